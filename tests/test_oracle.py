@@ -1,0 +1,305 @@
+"""Pins the CPU oracle (oracle/se_oracle.c) before anything trusts it:
+  * the reference's own known-answer values (tests/golden/ref_kats.json),
+  * golden vectors produced by the compiled reference (tests/golden/golden_*.{npz,json}),
+  * hashlib's SHAKE256 for the PRNG layer,
+  * and, when oracle/_ref/libse_ref.so is present, the compiled reference itself on fresh
+    random inputs.
+CPU only; runs in the build container and on the GPU box alike.
+"""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+import vectors as V
+from oracle import pyoracle
+from oracle.pyoracle import Oracle
+
+SEED_A = hashlib.shake_256(b"golden-share").digest(64)
+SEED_B = hashlib.shake_256(b"golden-secret").digest(64)
+SEED_PK = hashlib.shake_256(b"golden-pk").digest(64)
+SEED_EP = hashlib.shake_256(b"golden-ep").digest(64)
+
+
+def ends(a, k=8):
+    a = np.asarray(a).ravel()
+    return [int(x) for x in a[:k]] + [int(x) for x in a[-k:]]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    pyoracle.build(ref=True)
+
+
+# ---------------------------------------------------------------- reference's own KATs
+def test_barrett_kats(golden):
+    k = golden["kats"]
+    O = {134012929: (Oracle(1024, 1), 0), 1053818881: (Oracle(4096, 3), 0)}
+    for q, x, exp in k["barrett32"]:
+        o, j = O[q]
+        assert o.barrett32(x, j) == exp == x % q
+    for q, hi, lo, exp in k["barrett64"]:
+        o, j = O[q]
+        x = (hi << 32) | lo
+        assert o.barrett64(x, j) == exp == x % q
+    for q, a, b, exp in k["mul_mod"]:
+        o, j = O[q]
+        assert o.mul_mod(a, b, j) == exp
+
+
+def test_modarith_generic_cases():
+    # uintmodarith_tests.c:96-140 (parametrised on q)
+    for o in (Oracle(1024, 1), Oracle(4096, 3)):
+        q = o.q[0]
+        MAX = 0xFFFFFFFF
+        for a, b, e in [(0, 0, 0), (0, 1, 1), (0, q, 0), (1, q, 1), (1, q - 1, 0), (q, q - 2, q - 2),
+                        (q - 1, q - 1, q - 2), (0, 2 * q - 2, q - 2), (q - 10, q, q - 10),
+                        (q + 10, q - 12, q - 2)]:
+            assert o.add_mod(a, b) == e
+        for a, e in [(0, 0), (1, q - 1), (q - 1, 1), (q, 0), (10, q - 10), (q - 10, 10)]:
+            assert o.neg_mod(a) == e
+        for a, b, e in [(0, 0, 0), (1, 1, 1), (1, q, 0), (q + 1, 1, 1), (q - 1, 1, q - 1),
+                        (0, 12345, 0), (1, MAX, MAX % q), (1, 12345, 12345 % q)]:
+            assert o.mul_mod(a, b) == e
+
+
+def test_const_ratio_and_roots_tables():
+    for n, npr in V.ALL_SHAPES:
+        o = Oracle(n, npr)
+        for j in range(npr):
+            q = o.q[j]
+            ratio = (1 << 64) // q
+            assert (int(o.p.cr_hi[j]) << 32 | int(o.p.cr_lo[j])) == ratio
+            psi = int(o.p.psi[j])
+            assert pow(psi, n, q) == q - 1          # primitive 2n-th root of unity
+            assert (q - 1) % (2 * n) == 0
+
+
+# ---------------------------------------------------------------- PRNG layer
+def test_shake_matches_hashlib():
+    rng = np.random.default_rng(5)
+    for inlen in (0, 1, 71, 72, 135, 136, 137, 300):
+        msg = rng.integers(0, 256, inlen, dtype=np.uint8).tobytes()
+        for outlen in (1, 4, 96, 135, 136, 137, 1000):
+            assert Oracle.shake256(msg, outlen) == hashlib.shake_256(msg).digest(outlen)
+
+
+def test_prng_block_golden(golden):
+    for e in golden["digests"]["prng"]:
+        out = Oracle.prng_block(SEED_A, e["ctr"], e["len"])
+        assert hashlib.sha256(out).hexdigest() == e["sha256"]
+        assert out[:16].hex() == e["head"][:2 * min(16, e["len"])]
+        assert out == hashlib.shake_256(SEED_A + struct.pack("<Q", e["ctr"])).digest(e["len"])
+
+
+def test_keccak_zero_state_kat():
+    # Keccak-f[1600] on the all-zero state (well-known first lane of the KAT)
+    st = Oracle.keccak_f1600(np.zeros(25, dtype=np.uint64))
+    assert int(st[0]) == 0xF1258F7940E1DDE7
+    assert int(st[24]) == 0xEAF1FF7B5CECA249
+
+
+# ---------------------------------------------------------------- golden vectors (all shapes)
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_oracle_vs_golden(golden, shape):
+    n, npr = shape
+    d = golden["digests"]["shapes"][f"{n}x{npr}"]
+    o = Oracle(n, npr)
+    assert o.q == d["q"] and o.scale == d["scale"]
+    assert V.sha256_hex(o.map) == d["index_map_sha256"]
+
+    for t in range(9):
+        ok, m = o.encode(V.pattern_values(t, n))
+        assert ok and V.sha256_hex(m) == d["encode"][f"pattern{t}"]["sha256"]
+    ok, m = o.encode(V.bench_values(1, n)[0])
+    assert ok and V.sha256_hex(m) == d["encode"]["bench0"]["sha256"]
+    ok, _ = o.encode(np.full(n // 2, 3.0e38, dtype=np.float32))
+    assert ok == d["encode"]["overflow_3e38_ok"] and not ok
+
+    ctr = 0
+    for j in range(npr):
+        g = d["samplers"][f"uniform_p{j}"]
+        a, ctr2 = o.sample_uniform(j, SEED_A, ctr)
+        assert ctr == g["ctr_in"] and ctr2 == g["ctr_out"] and V.sha256_hex(a) == g["sha256"]
+        ctr = ctr2
+    u, c2 = o.sample_ternary_small(SEED_B, 0)
+    assert c2 == d["samplers"]["ternary"]["ctr_out"]
+    assert V.sha256_hex(u) == d["samplers"]["ternary"]["sha256"]
+    e, c3 = o.cbd_int8(SEED_B, c2)
+    assert c3 == d["samplers"]["cbd_int8"]["ctr_out"]
+    assert V.sha256_hex(e) == d["samplers"]["cbd_int8"]["sha256"]
+
+    rng = np.random.default_rng(d["ntt_random_seed"])
+    for j in range(npr):
+        q = o.q[j]
+        delta = np.zeros(n, dtype=np.uint32)
+        delta[1] = 1
+        ins = {"delta1": delta, "ones": np.ones(n, dtype=np.uint32),
+               "ramp": (np.arange(n, dtype=np.uint64) % q).astype(np.uint32),
+               "qm1": np.full(n, q - 1, dtype=np.uint32),
+               "random": rng.integers(0, q, n, dtype=np.uint64).astype(np.uint32)}
+        for name, x in ins.items():
+            assert V.sha256_hex(o.ntt(x, j)) == d["ntt"][f"{name}_p{j}"]["sha256"], (name, j)
+        assert V.sha256_hex(o.ntt_roots(j)) == d["ntt"][f"roots_p{j}"]["sha256"]
+
+    x = np.zeros(n, dtype=np.int64)
+    x[:6] = [0, -o.q[0], o.q[0], -1, 1, -(2 ** 62)]
+    assert [int(v) for v in o.reduce_pte(x, 0)[:6]] == d["reduce_edge"]
+    assert d["reduce_edge"][1] == o.q[0]          # the non-canonical q (ckks_common.c:234)
+
+    sk = V.secret_key(n)
+    for tag, vals, s1, s2 in [("survey", V.survey_values(n), V.SURVEY_SHARE_SEED, V.SURVEY_SEED),
+                              ("bench0", V.bench_values(1, n)[0], SEED_A, SEED_B)]:
+        g = d[f"sym_{tag}"]
+        r = o.encrypt_sym(vals, s1, s2, sk)
+        assert r["ok"] and r["end_ctr"] == g["end_ctr"]
+        assert V.sha256_hex(r["c0"]) == g["c0_sha256"]
+        assert V.sha256_hex(r["c1"]) == g["c1_sha256"]
+        assert V.sha256_hex(r["pte"]) == g["pte_sha256"]
+        assert V.sha256_hex(r["ntt_pte"]) == g["c1_alias_sha256"]   # the alias quirk, SURVEY 0.5
+        assert [ends(r["c0"][j]) for j in range(npr)] == g["c0_ends"]
+
+    g = d["asym_survey"]
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    assert V.sha256_hex(pk0) == g["pk0_sha256"] and V.sha256_hex(pk1) == g["pk1_sha256"]
+    r = o.encrypt_asym(V.survey_values(n), V.SURVEY_SEED, pk0, pk1)
+    assert r["ok"] and r["end_ctr"] == g["end_ctr"]
+    for key in ("c0", "c1", "pte", "u", "e1"):
+        assert V.sha256_hex(r[key]) == g[f"{key}_sha256"], key
+
+    # API-level callback stream (per prime: c0 then the aliased c1 buffer in sym mode)
+    r = o.encrypt_sym(V.survey_values(n), V.SURVEY_SHARE_SEED, V.SURVEY_SEED, sk)
+    stream = b"".join(r["c0"][j].tobytes() + r["ntt_pte"][j].tobytes() for j in range(npr))
+    assert "%016x" % pyoracle.fnv1a64(stream) == d["api_fnv1a64_sym"]
+    r = o.encrypt_asym(V.survey_values(n), V.SURVEY_SEED, pk0, pk1)
+    stream = b"".join(r["c0"][j].tobytes() + r["c1"][j].tobytes() for j in range(npr))
+    assert "%016x" % pyoracle.fnv1a64(stream) == d["api_fnv1a64_asym"]
+
+
+def test_full_vectors_c1(golden):
+    g = golden["c1"]
+    o = Oracle(1024, 1)
+    sk = V.secret_key(1024)
+    for t in range(9):
+        assert (o.encode(V.pattern_values(t, 1024))[1] == g[f"encode_pattern{t}"]).all()
+    assert (o.sample_uniform(0, SEED_A, 0)[0] == g["uniform_p0"]).all()
+    assert (o.sample_ternary_small(SEED_B, 0)[0] == g["ternary"]).all()
+    assert (o.ntt(g["ntt_random_in"], 0) == g["ntt_random_out"]).all()
+    r = o.encrypt_sym(V.survey_values(1024), V.SURVEY_SHARE_SEED, V.SURVEY_SEED, sk)
+    assert (r["c0"] == g["sym_c0"]).all() and (r["c1"] == g["sym_c1"]).all()
+    assert (r["pte"] == g["sym_pte"]).all() and (r["ntt_pte"] == g["sym_c1_alias"]).all()
+    # the value quoted in SURVEY.md section 0.8
+    assert [int(x) for x in r["c0"][0, :4]] == [2684880, 75498332, 27037551, 131419181]
+    ra = o.encrypt_asym(V.survey_values(1024), V.SURVEY_SEED, g["pk0"], g["pk1"])
+    assert (ra["c0"] == g["asym_c0"]).all() and (ra["c1"] == g["asym_c1"]).all()
+
+
+def test_twiddle_digest_matches_host_libm(golden):
+    """SURVEY trap T8: encode goldens assume this host's libm cos/sin equal the generating
+    host's.  If this fails on another box the encode goldens may differ in last-bit cases."""
+    for n, dg in golden["digests"]["ifft_twiddle_sha256"].items():
+        w = Oracle(int(n), 1).twiddles()
+        assert hashlib.sha256(w.astype("<f8").tobytes()).hexdigest() == dg
+
+
+# ---------------------------------------------------------------- properties
+def test_pseudo_decrypt_identity():
+    """c0 + c1 . NTT(s) == NTT(m + e) exactly (device/test/ckks_tests_common.c:206)."""
+    for n, npr in [(1024, 1), (4096, 3)]:
+        o = Oracle(n, npr)
+        sk = V.secret_key(n, seed=3)
+        r = o.encrypt_sym(V.bench_values(1, n)[0], SEED_A, SEED_B, sk)
+        for j in range(npr):
+            q = o.q[j]
+            s_hat = o.ntt(o.expand_ternary(sk, j), j).astype(np.uint64)
+            lhs = (r["c0"][j].astype(np.uint64) + r["c1"][j].astype(np.uint64) * s_hat % q) % q
+            assert (lhs == r["ntt_pte"][j]).all()
+
+
+def test_ntt_is_negacyclic_convolution():
+    """ntt(a) . ntt(b) == ntt(a*b mod (x^n+1)) against schoolbook (device/test/ntt_tests.c)."""
+    o = Oracle(1024, 1)
+    q, n = o.q[0], 1024
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, q, n, dtype=np.uint64)
+    b = np.zeros(n, dtype=np.uint64)
+    b[[0, 3, 700]] = [5, q - 2, 7]
+    prod = np.zeros(n, dtype=object)
+    for i in (0, 3, 700):
+        for k in range(n):
+            t = int(a[k]) * int(b[i])
+            idx = k + i
+            if idx >= n:
+                prod[idx - n] -= t
+            else:
+                prod[idx] += t
+    prod = np.array([int(x) % q for x in prod], dtype=np.uint32)
+    lhs = (o.ntt(a.astype(np.uint32), 0).astype(np.uint64) *
+           o.ntt(b.astype(np.uint32), 0).astype(np.uint64)) % q
+    assert (lhs.astype(np.uint32) == o.ntt(prod, 0)).all()
+
+
+def test_encode_decode_roundtrip_within_tolerance():
+    """FFT(decode) of the encoded polynomial returns the inputs within 0.1
+    (device/test/ckks_tests_common.c:132); done here with numpy's canonical embedding."""
+    n = 1024
+    o = Oracle(n, 1)
+    vals = V.pattern_values(8, n)
+    ok, m = o.encode(vals)
+    assert ok
+    # evaluate m(x) at zeta^(3^i), zeta = e^{i pi / n}
+    pos = 1
+    coeffs = m.astype(np.float64) / o.scale
+    for i in range(0, n // 2, 37):
+        p = pow(3, i, 2 * n)
+        z = np.exp(1j * np.pi * p / n)
+        val = np.polyval(coeffs[::-1], z)
+        assert abs(val.real - float(vals[i])) < 0.1 and abs(val.imag) < 0.1
+
+
+# ---------------------------------------------------------------- live reference cross-check
+@pytest.mark.ref
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("shape", [(1024, 1), (4096, 3), (16384, 6)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_oracle_vs_live_reference_random(shape):
+    from oracle.pyoracle import Reference
+    n, npr = shape
+    o, R = Oracle(n, npr), Reference(n, npr)
+    rng = np.random.default_rng(n)
+    sk = V.secret_key(n, seed=11)
+    R.set_sk(sk)
+    for trial in range(3):
+        vals = (rng.standard_normal(n // 2) * 10 ** trial).astype(np.float32)
+        s1 = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+        s2 = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+        a, b = o.encrypt_sym(vals, s1, s2, sk), R.encrypt_sym(vals, s1, s2)
+        for k in ("c0", "c1", "pte"):
+            assert (a[k] == b[k]).all(), k
+        assert a["end_ctr"] == b["end_ctr"]
+    # short input (zero fill) and ragged lengths
+    for vlen in (0, 1, 7, n // 2 - 1):
+        vals = rng.standard_normal(vlen).astype(np.float32)
+        a, b = o.encrypt_sym(vals, s1, s2, sk), R.encrypt_sym(vals, s1, s2)
+        assert (a["c0"] == b["c0"]).all() and (a["c1"] == b["c1"]).all()
+    # word-level cross-check on random operands
+    for j in range(npr):
+        for _ in range(200):
+            x = int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2))
+            assert o.barrett64(x, j) == R.barrett64(x, j) == x % o.q[j]
+            w = int(rng.integers(0, 2 ** 32))
+            assert o.barrett32(w, j) == R.barrett32(w, j) == w % o.q[j]
+    R.close()
+
+
+def test_batched_driver_matches_single():
+    n, npr, B = 1024, 1, 6
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n)
+    ss, sd = V.bench_seeds(B)
+    sk = V.secret_key(n)
+    ok, c0, c1 = o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=3)
+    assert ok
+    for b in range(B):
+        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (c0[b] == r["c0"]).all() and (c1[b] == r["c1"]).all()
