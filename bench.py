@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- batched CKKS encode+encrypt throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE env)
+
+A "step" is one pass of the hot path over one batch of synthetic plaintexts that are already
+resident in HBM.  Default workload = BASELINE config 2: n=4096, 3x30-bit primes, symmetric,
+batch 65536 PER GPU (weak scaling: every rank encrypts its own contiguous block of the batch
+index; no data-path collective).  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline     -- dominant kernel: algorithmic bytes per launch / its HIP-event-measured average
+                  duration, against the 8 TB/s HBM peak (MI355X_MICROARCH.md).
+  cpu_baseline -- the reference's CPU path (oracle/_ref, kind "reference") or our C restatement
+                  (kind "port") timed on this box's host cores on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (n, nprimes, mode, default batch per GPU, algorithmic bytes per unit)
+    # bytes per unit: sym = 2n + 128 + 8*n*np; asym = 2n + 64 + 8*n*np;
+    # encode-only = 2n + 4*n*np
+    "c1": (1024, 1, "sym", 1, 2 * 1024 + 128 + 8 * 1024 * 1),
+    "c2": (4096, 3, "sym", 65536, 2 * 4096 + 128 + 8 * 4096 * 3),
+    "c3": (4096, 3, "asym", 65536, 2 * 4096 + 64 + 8 * 4096 * 3),
+    "c4": (16384, 6, "sym", 32768, 2 * 16384 + 128 + 8 * 16384 * 6),
+    "c5": (4096, 3, "encode", 262144, 2 * 4096 + 4 * 4096 * 3),
+}
+DESCR = {
+    "c1": "C1: n=1024, 1x27-bit prime, symmetric encode+encrypt",
+    "c2": "C2: n=4096, 3x30-bit RNS primes, symmetric encode+encrypt",
+    "c3": "C3: n=4096, 3x30-bit RNS primes, asymmetric (pk) encode+encrypt",
+    "c4": "C4: n=16384, 6x30-bit RNS primes, symmetric encode+encrypt",
+    "c5": "C5: n=4096, 3x30-bit RNS primes, encode-only (IFFT + RNS reduce + NTT)",
+}
+
+
+def cpu_baseline(n, npr, mode, budget_s=12.0):
+    """Reference CPU path on this box's host cores over a bounded sample of the same workload
+    (region = encode + sampler init + per-prime encrypt, keys resident; bench_sym.c:96-130)."""
+    import numpy as np
+    import vectors as V
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    sk = V.secret_key(n)
+    use_ref = pyoracle.ref_available()
+    kind = "reference" if use_ref else "port"
+    if mode != "sym":
+        use_ref, kind = False, "port"   # batched reference driver exists for the symmetric path
+
+    def run(B):
+        vals = V.bench_values(B, n)
+        ss, sd = V.bench_seeds(B)
+        t0 = time.perf_counter()
+        if mode == "sym":
+            if use_ref:
+                pyoracle.Reference.encrypt_sym_batch(n, npr, vals, ss, sd, sk, nthreads=cores,
+                                                     keep=False)
+            else:
+                pyoracle.Oracle(n, npr).encrypt_sym_batch(vals, ss, sd, sk, nthreads=cores,
+                                                          keep=False)
+        else:
+            o = pyoracle.Oracle(n, npr)
+            if mode == "asym":
+                pk0, pk1 = o.gen_pk(sk, bytes(64), bytes(range(64)))
+                for b in range(B):
+                    o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+            else:
+                for b in range(B):
+                    ok, m = o.encode(vals[b])
+                    for j in range(npr):
+                        o.ntt(o.reduce_pte(m, j), j)
+        return time.perf_counter() - t0
+
+    threads = cores if mode == "sym" else 1
+    probe = max(threads * 4, 8)
+    t = run(probe)
+    B = int(max(probe, min(200000, probe * budget_s / max(t, 1e-6))))
+    B = max(threads, (B // threads) * threads)
+    t = run(B)
+    return {"value": B / t, "unit": "ciphertexts/s" if mode != "encode" else "plaintexts/s",
+            "cores": threads, "kind": kind,
+            "sample": f"{B} units of the same synthetic workload in {t:.2f} s on {threads} host "
+                      f"thread(s); {'oracle/_ref (compiled reference, -O3 -fno-strict-aliasing)' if use_ref else 'oracle/se_oracle.c (C restatement, -O2)'}",
+            "single_core_est": B / t / threads}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="batch per GPU (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time the final RCCL gather of ciphertext records to rank 0")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import vectors as V
+    import __graft_entry__ as ge
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, npr, mode, defB, bytes_per_unit = WORKLOADS[args.workload]
+    B = args.batch or defB
+    pkg = ge.load_package()
+    ctx = pkg.Context(n, npr, local_rank)
+    sk = V.secret_key(n)
+    if mode == "sym":
+        ctx.set_secret_key(sk)
+    elif mode == "asym":
+        # public key from fixed seeds through the oracle's gen_pk restatement (key-side tooling is
+        # outside the timed path; the reference takes pk from files the adapter wrote)
+        from oracle.pyoracle import Oracle
+        pk0, pk1 = Oracle(n, npr).gen_pk(sk, bytes(64), bytes(range(64)))
+        ctx.set_public_key(pk0, pk1)
+
+    # ---- synthetic inputs, resident in HBM before timing; rank r owns batch block r ----------
+    first = rank * B
+    vals = torch.from_numpy(V.bench_values(B, n, first=first)).to(dev)
+    ss_np, sd_np = V.bench_seeds(B, first=first)
+    ss, sd = torch.from_numpy(ss_np).to(dev), torch.from_numpy(sd_np).to(dev)
+    c0 = torch.empty((B, npr, n), dtype=torch.int32, device=dev)
+    c1 = torch.empty((B, npr, n), dtype=torch.int32, device=dev) if mode != "encode" else None
+    status = torch.zeros(B, dtype=torch.uint8, device=dev)
+
+    def step():
+        if mode == "sym":
+            ctx.encrypt_sym(vals, ss, sd, c0, c1, status=status)
+        elif mode == "asym":
+            ctx.encrypt_asym(vals, sd, c0, c1, status=status)
+        else:
+            ctx.encode_ntt(vals, c0, status=status)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.reserve(B)  # scratch allocation is not a step
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(status.all()), "an encode overflowed on synthetic data"
+
+    # ---- per-kernel durations with HIP events on the launch stream (separate profiled run) ---
+    ctx.set_profiling(True)
+    ctx.stage_ms(reset=True)
+    prof_steps = min(args.steps, 5)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    stages = ctx.stage_ms(reset=True)
+    ctx.set_profiling(False)
+    per_launch = {s: (ms / cnt if cnt else 0.0) for s, (ms, cnt) in stages.items()}
+    dominant = max(per_launch, key=per_launch.get)
+    dom_ms = per_launch[dominant]
+    kernel_names = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform",
+                    "ternary": "k_sample_ternary", "encode_encrypt": "k_encode_encrypt"}
+    achieved = bytes_per_unit * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            ent = tj.get(args.workload, {}).get(kernel_names[dominant])
+            if ent and ent.get("batch") == B:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": kernel_names[dominant], "kernel_ms": dom_ms,
+                "algorithmic_bytes_per_launch": bytes_per_unit * B,
+                "stage_ms_per_launch": per_launch,
+                "pipeline_frac": bytes_per_unit * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
+
+    gather = None
+    if args.gather and world > 1 and mode != "encode":
+        from seal_embedded_amd.sharding import gather_records
+        fence()
+        g0 = time.perf_counter()
+        for slab in (c0, c1):
+            gather_records(slab, dist, dst=0, chunk_records=4096)
+        fence()
+        gsec = time.perf_counter() - g0
+        gather = {"ms": gsec * 1e3, "bytes_into_root": 2 * (world - 1) * c0.numel() * 4,
+                  "GB/s": 2 * (world - 1) * c0.numel() * 4 / gsec / 1e9}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(n, npr, mode)
+
+    if rank == 0:
+        units = world * B * args.steps
+        line = {
+            "metric": "CKKS ciphertexts/s (batched encode+encrypt)" if mode != "encode"
+                      else "CKKS plaintexts/s (batched encode + RNS NTT)",
+            "value": units / elapsed,
+            "unit": "ciphertexts/s" if mode != "encode" else "plaintexts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": DESCR[args.workload] + f", batch={B} per GPU", "n": n,
+                       "nprimes": npr, "mode": mode, "batch_per_gpu": B,
+                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}",
+                       "bytes_per_unit": bytes_per_unit},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if gather:
+            line["gather"] = gather
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,227 @@
+/*
+ * seal_embedded_amd.h -- C ABI of the MI355X-native CKKS encode+encrypt library
+ *                        (libseal_embedded_amd.so).
+ *
+ * Two layers, both plain C (pointers and sizes only, no torch / C++ types):
+ *
+ *  1. The reference's own API surface for this path, same names / argument meaning / error
+ *     behaviour, so existing SEAL-Embedded callers link unchanged:
+ *        se_setup_custom, se_setup, se_setup_default, se_encrypt_seeded, se_encrypt, se_cleanup
+ *        (replaces /root/reference/device/lib/seal_embedded.h:91-130, seal_embedded.c:24-235)
+ *     Each call runs a batch of ONE through the GPU kernels.
+ *
+ *  2. Batched entry points (new): whole batches of independent plaintexts, host-pointer and
+ *     device-pointer flavours, plus stage-level batched operators that mirror the lower surface
+ *     the reference's tests/bench call directly (ckks_encode_base, ntt_inpl, prng_fill_buffer,
+ *     sample_poly_uniform, sample_small_poly_ternary_prng_96, sample_poly_cbd_generic_prng_16).
+ *
+ * Ciphertext layout everywhere: uint32 [ct][prime][coeff] -- per ciphertext the polynomials of
+ * prime 0..np-1, each n little-endian uint32 residues in [0,q_j), NTT form, bit-reversed order
+ * (ntt.h:19-24).  c0 and c1 are separate slabs of that shape; record b of c0 followed by record b
+ * of c1 per prime is exactly the byte stream the reference hands to its SEND_FNCT_PTR
+ * (seal_embedded.c:196-203).
+ *
+ * All functions return SE_SUCCESS (0) or a negative SE_ERR_* code unless stated otherwise.
+ * The library needs a HIP device: there is no CPU fallback; without one se_amd_create fails.
+ */
+#ifndef SEAL_EMBEDDED_AMD_H
+#define SEAL_EMBEDDED_AMD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: seal_embedded.h:35-40 --------------------------------------------------- */
+#define SE_SUCCESS 0
+#define SE_ERR_NO_MEMORY -12
+#define SE_ERR_INVALD_ARGUMENT -22
+#define SE_ERR_UNKNOWN -1000
+#define SE_ERR_MINIMUM -9999
+/* additions (inside the reserved range) */
+#define SE_ERR_NO_DEVICE -19
+#define SE_ERR_HIP -1001
+#define SE_ERR_NO_KEY -1002
+
+/* ---- reference types, same layout (defines.h:366-379, modulus.h:22-30, parameters.h:43-67,
+ *      ckks_common.h:36-52, seal_embedded.h:52-65; default config: SE_USE_MALLOC, 32-bit ZZ) ---- */
+typedef uint32_t ZZ;
+typedef float flpt;
+#define SE_PRNG_SEED_BYTE_COUNT 64 /* defines.h:67 */
+
+typedef struct Modulus
+{
+    ZZ value;
+    ZZ const_ratio[2]; /* floor(2^64/q): low word, high word */
+} Modulus;
+
+typedef struct
+{
+    size_t coeff_count;
+    size_t logn;
+    Modulus *moduli;
+    Modulus *curr_modulus;
+    size_t curr_modulus_idx;
+    size_t nprimes;
+    double scale;
+    bool is_asymmetric;
+    bool pk_from_file;
+    bool sample_s;
+    bool small_s;
+    bool small_u;
+} Parms;
+
+typedef struct SE_PTRS
+{
+    double *conj_vals;  /* n complex128 (re,im interleaved); first 8n bytes hold int64 plaintext */
+    double *ifft_roots; /* unused (roots live on the device) */
+    flpt *values;       /* n/2 floats */
+    ZZ *ternary;        /* 2-bit packed s (sym) / u (asym), n/4 bytes */
+    int64_t *conj_vals_int_ptr;
+    ZZ *c0_ptr; /* n residues of the current prime (host staging buffer) */
+    ZZ *c1_ptr;
+    uint16_t *index_map_ptr;
+    ZZ *ntt_roots_ptr; /* unused (tables live on the device) */
+    ZZ *ntt_pte_ptr;
+    int8_t *e1_ptr;
+} SE_PTRS;
+
+typedef struct
+{
+    Parms *parms;
+    SE_PTRS *se_ptrs;
+} SE_PARMS;
+
+typedef enum { SE_SYM_ENCR, SE_ASYM_ENCR } EncryptType;
+typedef size_t (*SEND_FNCT_PTR)(void *, size_t);
+
+/* ---- layer 1: the reference API (seal_embedded.h:91-130) ----------------------------------
+ * Behaviour kept: default parameter sets only (custom moduli are unreachable in the reference,
+ * ckks_common.c:90); `scale` is overridden by the parameter set (parameters.c:190-226); one
+ * parameter set per process (static singletons, seal_embedded.c:18-22); the secret key is read
+ * from <SE_DATA_PATH>/sk_<n>.dat and the public key from pk{0,1}_ntt_<n>_<q>.dat relative to the
+ * CWD (fileops.c:140-204; SE_DATA_PATH = "adapter_output_data", overridable through the
+ * SE_AMD_DATA_PATH environment variable); NULL seeds draw from getrandom (rng.h:45-53); the
+ * callback receives c0 then c1 of each prime, n*4 bytes each, from library-owned buffers.
+ * Divergence (documented in DESIGN.md): in symmetric mode the reference's default build hands
+ * the callback ntt(m+e) in place of c1 because the two buffers alias (ckks_sym.c:86-88).  We
+ * deliver the correct c1 = a unless SE_AMD_REFERENCE_C1_ALIAS=1 is set in the environment, in
+ * which case the reference's byte stream is reproduced bit for bit. */
+SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals, const ZZ *ratios,
+                          double scale, EncryptType encrypt_type);
+SE_PARMS *se_setup(size_t degree, size_t nprimes, double scale, EncryptType encrypt_type);
+SE_PARMS *se_setup_default(EncryptType encrypt_type);
+bool se_encrypt_seeded(uint8_t *shareable_seed, uint8_t *seed, SEND_FNCT_PTR network_send_function,
+                       void *v, size_t vlen_bytes, bool print, SE_PARMS *se_parms);
+bool se_encrypt(SEND_FNCT_PTR network_send_function, void *v, size_t vlen_bytes, bool print,
+                SE_PARMS *se_parms);
+void se_cleanup(SE_PARMS *se_parms);
+
+/* New beside them: batched host-pointer entry on the handle se_setup returned.
+ * values [B][n/2] float; share_seeds [B][64] (ignored for asymmetric; may be NULL then);
+ * seeds [B][64]; c0, c1 [B][np][n] uint32 out.  Returns SE_SUCCESS, or the number (>0) of
+ * plaintexts whose encoding overflowed int64 (their records are unspecified), or SE_ERR_*. */
+int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
+                     const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1);
+
+/* ---- layer 2: explicit context, batched, device pointers ---------------------------------- */
+typedef struct se_amd_ctx se_amd_ctx;
+
+/* Builds the parameter set (parameters.c:176-230), the index map (ckks_common.c:32-68), the IFFT
+ * root table with the HOST libm (fft.c:39-45) and the per-prime NTT root tables (ntt.c:24-60)
+ * and uploads them to HIP device `device`. */
+int se_amd_create(se_amd_ctx **out, size_t degree, size_t nprimes, int device);
+void se_amd_destroy(se_amd_ctx *ctx);
+
+/* parameter read-back */
+size_t se_amd_degree(const se_amd_ctx *ctx);
+size_t se_amd_nprimes(const se_amd_ctx *ctx);
+double se_amd_scale(const se_amd_ctx *ctx);
+int se_amd_moduli(const se_amd_ctx *ctx, uint32_t *q /*[np]*/);
+int se_amd_index_map(const se_amd_ctx *ctx, uint16_t *map /*[n], host*/);
+
+/* keys (host pointers).  sk: 2-bit packed, n/4 bytes, sk_<n>.dat format.  pk: [np][n] uint32,
+ * NTT form, the pk{0,1}_ntt_<n>_<q>.dat payloads concatenated over primes. */
+int se_amd_set_secret_key(se_amd_ctx *ctx, const uint8_t *sk_packed);
+int se_amd_set_public_key(se_amd_ctx *ctx, const uint32_t *pk0, const uint32_t *pk1);
+int se_amd_load_keys_from_dir(se_amd_ctx *ctx, const char *dir, int want_pk);
+
+/* Whole path, device pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Optional outputs may be NULL: ntt_pte [B][np][n] = NTT(m+e mod q_j); pte [B][n] int64;
+ * status [B] bytes (1 ok / 0 encode overflow).  Internal scratch is grown on demand (not
+ * stream-ordered: call once with the largest B before timing). */
+int se_amd_encrypt_sym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
+                              const uint8_t *d_share_seeds, const uint8_t *d_seeds, uint32_t *d_c0,
+                              uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte,
+                              uint8_t *d_status, void *stream);
+int se_amd_encrypt_asym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
+                               const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
+                               uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
+                               void *stream);
+/* BASELINE config 5: encode + RNS reduce + NTT only; out [B][np][n] = NTT(m mod q_j). */
+int se_amd_encode_ntt_device(se_amd_ctx *ctx, const float *d_values, size_t B, uint32_t *d_out,
+                             int64_t *d_pte, uint8_t *d_status, void *stream);
+
+/* Host-pointer convenience wrappers (H2D, run, D2H, synchronous). */
+int se_amd_encrypt_sym_host(se_amd_ctx *ctx, const float *values, size_t B,
+                            const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0,
+                            uint32_t *c1, uint32_t *ntt_pte, int64_t *pte, uint8_t *status);
+int se_amd_encrypt_asym_host(se_amd_ctx *ctx, const float *values, size_t B, const uint8_t *seeds,
+                             uint32_t *c0, uint32_t *c1, uint32_t *ntt_pte, int64_t *pte,
+                             uint8_t *status);
+
+/* ---- stage-level batched operators (device pointers) -------------------------------------- */
+/* ckks_encode_base (ckks_common.c:105-215): values [B][n/2] -> int64 [B][n]; status [B]. */
+int se_amd_encode_device(se_amd_ctx *ctx, const float *d_values, size_t B, int64_t *d_out,
+                         uint8_t *d_status, void *stream);
+/* ntt_inpl (ntt.c:168-189) for prime j on `count` polynomials [count][n], in place. */
+int se_amd_ntt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t count, void *stream);
+/* prng_fill_buffer (rng.h:78-91): out[i] = SHAKE256(seed[i] || le64(ctr[i]))[0:outlen]. */
+int se_amd_prng_blocks_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctrs,
+                              uint8_t *d_out, size_t outlen, size_t count, void *stream);
+/* sample_poly_uniform for primes 0..np-1 in chain order (sample.c:39-57): out [B][np][n];
+ * d_ctr_in may be NULL (= 0); d_ctr_out optional [B]. */
+int se_amd_sample_uniform_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctr_in,
+                                 size_t B, uint32_t *d_out, uint64_t *d_ctr_out, void *stream);
+/* sample_small_poly_ternary_prng_96 (sample.c:218-242): one int8 code (0,1,2) per coefficient
+ * [B][n] (the 2-bit packing of sample.c:61-87 is applied by se_amd_pack_ternary_host). */
+int se_amd_sample_ternary_device(se_amd_ctx *ctx, const uint8_t *d_seeds, size_t B, int8_t *d_codes,
+                                 uint64_t *d_ctr_out, void *stream);
+/* sample_poly_cbd_generic_prng_16 (sample.c:311-321): int8 [B][blocks*16], block k of ciphertext
+ * b uses counter ctr_base[b] + k (ctr_base NULL = 0). */
+int se_amd_sample_cbd_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctr_base,
+                             size_t B, size_t blocks_per_ct, int8_t *d_out, void *stream);
+void se_amd_pack_ternary_host(const int8_t *codes, size_t n, uint8_t *packed /*[n/4]*/);
+
+/* ---- profiling hooks ---------------------------------------------------------------------- */
+/* When enabled, every kernel launched by the whole-path entries is bracketed by HIP events on the
+ * caller's stream; after a stream sync se_amd_stage_ms returns the accumulated milliseconds and
+ * launch counts per stage since the last reset. */
+enum
+{
+    SE_AMD_STAGE_CBD = 0,
+    SE_AMD_STAGE_UNIFORM = 1,
+    SE_AMD_STAGE_TERNARY = 2,
+    SE_AMD_STAGE_ENCODE_ENCRYPT = 3,
+    SE_AMD_STAGE_COUNT = 4
+};
+int se_amd_set_profiling(se_amd_ctx *ctx, int enabled);
+int se_amd_stage_ms(se_amd_ctx *ctx, float *ms /*[SE_AMD_STAGE_COUNT]*/,
+                    uint64_t *launches /*[SE_AMD_STAGE_COUNT]*/, int reset);
+/* test hook: capacity of the per-ciphertext rejection list of the uniform sampler (default 256);
+ * tiny values force the overflow path. */
+int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
+/* Pre-allocate the internal scratch for batches of up to B plaintexts (keeps hipMalloc out of
+ * the first timed call). */
+int se_amd_reserve(se_amd_ctx *ctx, size_t B);
+const char *se_amd_last_error(void);
+const char *se_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEAL_EMBEDDED_AMD_H */

@@ -1,0 +1,364 @@
+// encode_encrypt.hip -- one workgroup per plaintext: CKKS encode (FP64 inverse FFT) -> add the
+// sampled error -> per RNS prime {signed reduction -> forward NTT -> fused ciphertext arithmetic}.
+//
+// Replaces, for a whole batch at once:
+//   ckks_encode_base          /root/reference/device/lib/ckks_common.c:105-215
+//   ifft_inpl                 /root/reference/device/lib/fft.c:69-144
+//   reduce_set_pte / _e_small /root/reference/device/lib/ckks_common.c:224-265
+//   ntt_inpl                  /root/reference/device/lib/ntt.c:124-189
+//   the per-prime bodies of ckks_encode_encrypt_sym (ckks_sym.c:199-301) and
+//   ckks_encode_encrypt_asym (ckks_asym.c:205-286) incl. poly_*_mod_inpl (polymodarith.h:39-101)
+//
+// Data never leaves the CU between encode and the final store: the plaintext stays in VGPRs
+// (int64 x 16 per thread) across all primes; LDS is only the re-deal buffer of the transforms.
+// HBM traffic per ciphertext = values (2n B) + error bytes + a (read back, 4n*np) + c0 (4n*np).
+//
+// NTT(s) is a per-key constant: it is computed once when the key is set (k_ntt_polys below)
+// instead of once per ciphertext as the reference does -- same values, 1/2 of the NTT work.
+#include <hip/hip_runtime.h>
+
+#include "../se_types.h"
+#include "kernel_args.h"
+#include "transform.cuh"
+
+namespace seamd {
+
+
+__device__ __forceinline__ void load16(uint32_t (&v)[16], const uint32_t *p)
+{
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        uint4 w      = p4[i];
+        v[4 * i]     = w.x;
+        v[4 * i + 1] = w.y;
+        v[4 * i + 2] = w.z;
+        v[4 * i + 3] = w.w;
+    }
+}
+
+__device__ __forceinline__ void store16(uint32_t *p, const uint32_t (&v)[16])
+{
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) p4[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+// 16 interleaved (value, shoup) pairs starting at pair index `first`
+__device__ __forceinline__ void load16_pairs(uint32_t (&w)[16], uint32_t (&wp)[16],
+                                             const uint32_t *tab, size_t first)
+{
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(tab + 2 * first);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        uint4 v       = p4[i];
+        w[2 * i]      = v.x;
+        wp[2 * i]     = v.y;
+        w[2 * i + 1]  = v.z;
+        wp[2 * i + 1] = v.w;
+    }
+}
+
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(DevParams P, DevTables T,
+                                                                          EncArgs A)
+{
+    using G            = XformGeom<LOGN>;
+    constexpr int N    = G::N;
+    constexpr int TH   = G::THREADS;
+    constexpr int CTOP = LOGN - 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *plane   = reinterpret_cast<double *>(smem);
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
+    float *sv       = reinterpret_cast<float *>(smem);
+
+    const int t    = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int np   = P.nprimes;
+
+    // ---- 1. values -> LDS (coalesced), then gather through the inverse index map -----------
+    // ckks_common.c:139-153 scatters values[i] to both conjugate slots; the map is a bijection
+    // onto [0,n), so slot k is filled from values[inv_map[k] mod n/2].
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(A.values + b * (N / 2));
+        float4 *dst       = reinterpret_cast<float4 *>(sv);
+#pragma unroll
+        for (int i = t; i < N / 8; i += TH) dst[i] = src[i];
+    }
+    __syncthreads();
+    double re[16], im[16];
+    {
+        const uint4 *mp = reinterpret_cast<const uint4 *>(T.inv_map + 16 * t);
+        uint4 m0 = mp[0], m1 = mp[1];
+        uint32_t packed[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            uint32_t idx = (packed[e >> 1] >> (16 * (e & 1))) & (N / 2 - 1);
+            re[e]        = (double)sv[idx];
+            im[e]        = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183) ----------------------
+    ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
+
+    // ---- 3. round to int64, overflow check, add the error polynomial -------------------------
+    int64_t m[16];
+    int ok = 1;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        double c = round(__dmul_rn(re[e], P.n_inv));
+        if (fabs(c) > 9223372036854775808.0) ok = 0;
+        m[e] = (int64_t)c;
+    }
+    ok = __syncthreads_and(ok);
+    if (A.status && t == 0) A.status[b] = (uint8_t)ok;
+
+    // thread t now owns points k = t + (n/16)*e
+    if constexpr (MODE == kModeSym)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) m[e] += A.err[b * N + (e << CTOP) + t];
+    }
+    else if constexpr (MODE == kModeAsym)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) m[e] += A.err[b * 2 * N + (e << CTOP) + t];
+    }
+    if (A.pte)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) A.pte[b * N + (e << CTOP) + t] = m[e];
+    }
+
+    // ---- 4. per prime ----------------------------------------------------------------------
+    if constexpr (MODE == kModeEncodeOnly)
+    {
+        if (!A.c0) return;  // plain ckks_encode_base: only the int64 plaintext was requested
+    }
+    for (int j = 0; j < np; j++)
+    {
+        const uint32_t q = P.q[j], two_q = q << 1;
+        const uint32_t crh = P.cr_hi[j], crl = P.cr_lo[j];
+        const uint32_t *RW = T.ntt_rw + (size_t)2 * N * j;
+        const size_t off   = (b * np + j) * N + 16 * t;  // this thread's 16 output coefficients
+        uint32_t x[16];
+
+        if constexpr (MODE == kModeAsym)
+        {
+            // u_hat = NTT(expand(u))   (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1)
+            uint32_t uh[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
+                uh[e]         = code + (code == 0 ? q : 0u) - 1u;
+            }
+            ntt_tiles<LOGN>(uh, RW, q, lds32, t);
+            // c1 = pk1 . u_hat + NTT(e1)   (:251, :263-272)
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                int32_t e1 = A.err[b * 2 * N + N + (e << CTOP) + t];
+                x[e]       = (e1 < 0 ? q : 0u) + (uint32_t)e1;
+            }
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            {
+                uint32_t w[16], wp[16], out[16];
+                load16_pairs(w, wp, T.pk1, (size_t)j * N + 16 * t);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
+                    out[e]      = csub(pr + canon4(x[e], q, two_q), q);
+                }
+                store16(A.c1 + off, out);
+            }
+            // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = reduce_signed(m[e], q, crh, crl);
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+            if (A.ntt_pte) store16(A.ntt_pte + off, x);
+            {
+                uint32_t w[16], wp[16], out[16];
+                load16_pairs(w, wp, T.pk0, (size_t)j * N + 16 * t);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
+                    out[e]      = csub(pr + x[e], q);
+                }
+                store16(A.c0 + off, out);
+            }
+        }
+        else
+        {
+            // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = reduce_signed(m[e], q, crh, crl);
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+            if (A.ntt_pte) store16(A.ntt_pte + off, x);
+            if constexpr (MODE == kModeSym)
+            {
+                // c0 = -(s_hat . a) + NTT(m+e)   (ckks_sym.c:273-300); a was written to c1
+                uint32_t a[16], w[16], wp[16], out[16];
+                load16(a, A.c1 + off);
+                load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
+                    out[e]      = csub(x[e] + q - pr, q);
+                }
+                store16(A.c0 + off, out);
+            }
+            else
+            {
+                store16(A.c0 + off, x);
+            }
+        }
+    }
+}
+
+// Batched stand-alone forward NTT (ntt_inpl, ntt.c:168-189) of `count` polynomials mod q_j,
+// in place, natural-order in, bit-reversed-order canonical out.  Also emits the Shoup companion
+// table when `pairs_out` is given (used once per key for NTT(s) and the public key).
+template <int LOGN>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_ntt_polys(DevParams P, DevTables T, int j,
+                                                                     uint32_t *polys,
+                                                                     uint32_t *pairs_out)
+{
+    using G            = XformGeom<LOGN>;
+    constexpr int N    = G::N;
+    constexpr int CTOP = LOGN - 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
+    const int t     = threadIdx.x;
+    uint32_t *poly  = polys + (size_t)blockIdx.x * N;
+    const uint32_t q = P.q[j], two_q = q << 1;
+    uint32_t x[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = poly[(e << CTOP) + t];
+    ntt_tiles<LOGN>(x, T.ntt_rw + (size_t)2 * N * j, q, lds32, t);
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+    store16(poly + 16 * t, x);
+    if (pairs_out)
+    {
+        uint32_t *po = pairs_out + ((size_t)blockIdx.x * N + 16 * t) * 2;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            po[2 * e]     = x[e];
+            po[2 * e + 1] = (uint32_t)((((uint64_t)x[e]) << 32) / q);
+        }
+    }
+}
+
+// Shoup companions for a table that is already in NTT form (public-key slabs): pairs[i] =
+// (v[i], floor(v[i] * 2^32 / q_j)).
+__global__ void k_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, int count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+    {
+        uint32_t v       = vals[i];
+        pairs[2 * i]     = v;
+        pairs[2 * i + 1] = (uint32_t)((((uint64_t)v) << 32) / q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (called from se_context.cpp)
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+static hipError_t launch_enc(const DevParams &P, const DevTables &T, const EncArgs &A, int mode,
+                             size_t B, hipStream_t st)
+{
+    using G        = XformGeom<LOGN>;
+    size_t shmem   = (size_t)G::SLOTS * sizeof(double);
+    dim3 grid((unsigned)B), block(G::THREADS);
+    switch (mode)
+    {
+        case kModeSym:
+            (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeSym>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeSym>), grid, block, shmem, st, P, T, A);
+            break;
+        case kModeAsym:
+            (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeAsym>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeAsym>), grid, block, shmem, st, P, T, A);
+            break;
+        default:
+            (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeEncodeOnly>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeEncodeOnly>), grid, block, shmem, st, P,
+                               T, A);
+            break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_encrypt(const DevParams &P, const DevTables &T, const EncArgs &A, int mode,
+                                 size_t B, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    switch (P.logn)
+    {
+        case 10: return launch_enc<10>(P, T, A, mode, B, st);
+        case 11: return launch_enc<11>(P, T, A, mode, B, st);
+        case 12: return launch_enc<12>(P, T, A, mode, B, st);
+        case 13: return launch_enc<13>(P, T, A, mode, B, st);
+        case 14: return launch_enc<14>(P, T, A, mode, B, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_ntt(const DevParams &P, const DevTables &T, int j, uint32_t *polys,
+                             uint32_t *pairs, size_t count, hipStream_t st)
+{
+    using G      = XformGeom<LOGN>;
+    size_t shmem = (size_t)G::SLOTS * sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void *)k_ntt_polys<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)shmem);
+    hipLaunchKernelGGL((k_ntt_polys<LOGN>), dim3((unsigned)count), dim3(G::THREADS), shmem, st, P, T,
+                       j, polys, pairs);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_polys(const DevParams &P, const DevTables &T, int j, uint32_t *polys,
+                            uint32_t *pairs, size_t count, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    switch (P.logn)
+    {
+        case 10: return launch_ntt<10>(P, T, j, polys, pairs, count, st);
+        case 11: return launch_ntt<11>(P, T, j, polys, pairs, count, st);
+        case 12: return launch_ntt<12>(P, T, j, polys, pairs, count, st);
+        case 13: return launch_ntt<13>(P, T, j, polys, pairs, count, st);
+        case 14: return launch_ntt<14>(P, T, j, polys, pairs, count, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, size_t count,
+                             hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_make_pairs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, vals,
+                       pairs, q, (int)count);
+    return hipGetLastError();
+}
+
+}  // namespace seamd

@@ -1,0 +1,64 @@
+// kernel_args.h -- argument blocks and launcher prototypes shared by the kernels and the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../se_types.h"
+
+namespace seamd {
+
+struct EncArgs
+{
+    const float *values;
+    const int8_t *err;
+    const int8_t *ucodes;
+    uint32_t *c0;
+    uint32_t *c1;
+    uint32_t *ntt_pte;
+    int64_t *pte;
+    uint8_t *status;
+};
+struct UniformArgs
+{
+    const uint8_t *seeds;
+    const uint64_t *ctr_in;
+    uint64_t *ctr_out;
+    uint32_t *out;
+    uint32_t *rej_list;
+    uint32_t rej_cap;
+    uint32_t B;
+    uint32_t prime_lo, prime_hi;
+    uint32_t out_primes;
+};
+struct CbdArgs
+{
+    const uint8_t *seeds;
+    const uint64_t *ctr_base;
+    int8_t *out;
+    uint32_t blocks_per_ct;
+    uint32_t B;
+};
+struct TernaryArgs
+{
+    const uint8_t *seeds;
+    int8_t *codes;
+    uint64_t *ctr_out;
+    uint32_t n;
+    uint32_t B;
+};
+
+hipError_t launch_encode_encrypt(const DevParams &, const DevTables &, const EncArgs &, int mode,
+                                 size_t B, hipStream_t);
+hipError_t launch_ntt_polys(const DevParams &, const DevTables &, int j, uint32_t *polys,
+                            uint32_t *pairs, size_t count, hipStream_t);
+hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, size_t count,
+                             hipStream_t);
+hipError_t launch_sample_uniform(const DevParams &, const UniformArgs &, hipStream_t);
+hipError_t launch_sample_cbd(const CbdArgs &, hipStream_t);
+hipError_t launch_sample_ternary(const TernaryArgs &, hipStream_t);
+hipError_t launch_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs, uint8_t *out,
+                              uint32_t outlen, uint32_t count, hipStream_t);
+
+
+}  // namespace seamd

@@ -1,0 +1,69 @@
+// modarith.cuh -- 32-bit residue arithmetic kept in registers (device inlines).
+//
+// Replaces the word layer of the reference: device/lib/modulo.h:21-116 (shift_result, Barrett
+// 32->32 and 64->32), device/lib/uintmodarith.h:26-128 (add/neg/sub/mul mod) and the lazy
+// Harvey/Shoup form of uintmodarith.h:293-346 (MUMO).  All results that leave a kernel are
+// canonical residues in [0,q), i.e. equal to the reference's element for element; inside the
+// NTT values float in [0,4q) (q < 2^30 for every prime of parameters.c:129-174).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace seamd {
+
+// x in [0,2q) -> [0,q): unsigned min trick, 2 VALU ops, no compare/select.
+__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t q)
+{
+    return min(x, x - q);
+}
+
+// Shoup product y*w mod q in [0,2q) for ANY 32-bit y, given wp = floor(w * 2^32 / q).
+__device__ __forceinline__ uint32_t mul_shoup_lazy(uint32_t y, uint32_t w, uint32_t wp, uint32_t q)
+{
+    uint32_t h = __umulhi(y, wp);
+    return y * w - h * q;
+}
+
+// x mod q for a full 32-bit x (modulo.h:43-75): one mul_hi with floor(2^32/q).
+__device__ __forceinline__ uint32_t barrett32(uint32_t x, uint32_t q, uint32_t cr_hi)
+{
+    uint32_t est = __umulhi(x, cr_hi);
+    return csub(x - est * q, q);
+}
+
+// x mod q for a 64-bit x (modulo.h:84-116), ratio = floor(2^64/q) as (hi,lo).
+__device__ __forceinline__ uint32_t barrett64(uint64_t x, uint32_t q, uint32_t cr_hi, uint32_t cr_lo)
+{
+    uint64_t ratio = ((uint64_t)cr_hi << 32) | cr_lo;
+    uint64_t est   = __umul64hi(x, ratio);
+    uint32_t r     = (uint32_t)x - (uint32_t)est * q;  // true remainder is in [0,2q): 32 bits suffice
+    return csub(r, q);
+}
+
+// signed 64-bit plaintext coefficient -> residue (ckks_common.c:224-237).  The reference maps a
+// negative multiple of q to the non-canonical value q; the NTT that follows absorbs it
+// (add_mod/sub_mod subtract q once), so feeding q here is equivalent -- we keep it identical.
+__device__ __forceinline__ uint32_t reduce_signed(int64_t x, uint32_t q, uint32_t cr_hi, uint32_t cr_lo)
+{
+    uint64_t mag = x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x;
+    uint32_t r   = barrett64(mag, q, cr_hi, cr_lo);
+    return x < 0 ? q - r : r;
+}
+
+// Harvey butterfly, inputs/outputs in [0,4q): (X, Y) -> (X + Y*w, X - Y*w)  (ntt.c:156-162)
+__device__ __forceinline__ void ct_butterfly(uint32_t &x, uint32_t &y, uint32_t w, uint32_t wp,
+                                             uint32_t q, uint32_t two_q)
+{
+    uint32_t u = min(x, x - two_q);
+    uint32_t t = mul_shoup_lazy(y, w, wp, q);
+    x          = u + t;
+    y          = u - t + two_q;
+}
+
+// [0,4q) -> [0,q)
+__device__ __forceinline__ uint32_t canon4(uint32_t x, uint32_t q, uint32_t two_q)
+{
+    return csub(min(x, x - two_q), q);
+}
+
+}  // namespace seamd

@@ -1,0 +1,398 @@
+// samplers.hip -- SHAKE256-expanded polynomial samplers, one Keccak state per lane.
+//
+// Replaces (batched):
+//   prng_fill_buffer                        /root/reference/device/lib/rng.h:78-91
+//   sample_poly_uniform                     /root/reference/device/lib/sample.c:39-57
+//   sample_small_poly_ternary_prng_96       /root/reference/device/lib/sample.c:218-242
+//   sample_poly_cbd_generic_prng_16 and
+//   sample_add_poly_cbd_generic_inpl_prng_16 /root/reference/device/lib/sample.c:311-356
+//
+// The PRNG stream semantics are reproduced exactly, including the data-dependent counters:
+//   * uniform: block(ctr) of 4n bytes, then ONE fresh 4-byte block per rejection draw, consumed
+//     in coefficient order; the next prime continues at the next free counter.  Because every
+//     redraw is an independent SHAKE call, "the k-th rejected coefficient takes the k-th accepted
+//     candidate of the stream V[c] = block(c)[0:4], c = ctr+1, ctr+2, .." -- that is what the
+//     second phase computes.
+//   * ternary: 96-byte block per 96 coefficients, 1-byte redraw blocks interleaved between blocks.
+//   * CBD: counters are static (base + k), fully parallel.
+#include <hip/hip_runtime.h>
+
+#include "../se_types.h"
+#include "kernel_args.h"
+#include "keccak.cuh"
+#include "modarith.cuh"
+
+namespace seamd {
+
+__device__ __forceinline__ void load_seed(uint32_t (&seed)[16], const uint8_t *seeds, size_t b)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(seeds + b * kSeedBytes);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        uint4 v         = p[i];
+        seed[4 * i]     = v.x;
+        seed[4 * i + 1] = v.y;
+        seed[4 * i + 2] = v.z;
+        seed[4 * i + 3] = v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Uniform `a` for all primes of one ciphertext per lane.
+//
+// Output coalescing: a lane produces 136 contiguous bytes of ITS polynomial per permutation, 64
+// lanes write to 64 different polynomials.  Words go to a 256-byte per-lane LDS ring; whenever a
+// 128-byte line of the output is complete the wave stores it cooperatively (8 lanes x 16 B per
+// line, 8 lines per instruction), so HBM sees full 128-byte lines.
+// Rejected positions are recorded in a per-ciphertext list in HBM scratch (REJ_CAP entries) and
+// patched in phase 2; beyond REJ_CAP the lane rescans its own output for the marker word.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid residue
+
+
+template <int LOGN>
+__global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs A)
+{
+    constexpr int N           = 1 << LOGN;
+    constexpr int LINES       = N * 4 / 128;             // 128-byte lines per polynomial
+    constexpr int STEPS       = (N * 4 + 135) / 136;     // permutations of the bulk block
+    constexpr int RING_WORDS  = 64;                      // 256 B per lane
+    __shared__ __attribute__((aligned(16))) uint32_t ring[64 * RING_WORDS];
+
+    const int lane     = threadIdx.x;
+    const size_t b0    = (size_t)blockIdx.x * 64;
+    const size_t b     = b0 + lane;
+    const bool active  = b < A.B;
+    const size_t bsafe = active ? b : (size_t)A.B - 1;
+
+    uint32_t seed[16];
+    load_seed(seed, A.seeds, bsafe);
+    uint64_t ctr = A.ctr_in ? A.ctr_in[bsafe] : 0;
+    uint32_t *myring = ring + lane * RING_WORDS;
+    uint32_t *mylist = A.rej_list + bsafe * A.rej_cap;
+
+    for (uint32_t j = A.prime_lo; j < A.prime_hi; j++)
+    {
+        const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
+        uint32_t *poly_base = A.out + (b0 * A.out_primes + j) * (size_t)N;  // lane 0's polynomial
+        const size_t poly_stride = (size_t)A.out_primes * N;                // between lanes
+
+        KeccakState st;
+        prng_absorb(st, seed, ctr);
+        ctr++;
+        uint32_t nrej = 0;
+        int produced  = 0;  // words written to the ring so far (uniform across lanes)
+        int flushed   = 0;  // lines stored so far
+
+        auto emit = [&](uint32_t x, int widx) {
+            // widx = coefficient index (uniform).  Reject test and reduction: sample.c:50-56
+            bool rej = x >= bound;
+            uint32_t r = barrett32(x, q, crh);
+            if (widx < N)
+            {
+                if (rej)
+                {
+                    if (nrej < A.rej_cap) mylist[nrej] = (uint32_t)widx;
+                    nrej++;
+                }
+                myring[widx & (RING_WORDS - 1)] = rej ? kRejMarker : r;
+            }
+        };
+        auto flush_ready = [&]() {
+            // store every complete, not yet stored line (at most one per call by construction)
+            while ((flushed + 1) * 32 <= produced && flushed < LINES)
+            {
+                const int ring_off = (flushed & 1) * 32;  // words
+#pragma unroll
+                for (int it = 0; it < 8; it++)
+                {
+                    const int src = (lane >> 3) + 8 * it;          // which lane's polynomial
+                    const int seg = lane & 7;                      // 16-byte segment of the line
+                    uint4 v = *reinterpret_cast<const uint4 *>(ring + src * RING_WORDS + ring_off + 4 * seg);
+                    if (b0 + src < A.B)
+                    {
+                        uint32_t *dst = poly_base + src * poly_stride + flushed * 32 + 4 * seg;
+                        *reinterpret_cast<uint4 *>(dst) = v;
+                    }
+                }
+                flushed++;
+            }
+        };
+
+        for (int step = 0; step < STEPS; step++)
+        {
+            keccak_f1600(st);
+            const int base = step * 34;
+            // first 16 words (state lanes 0..7), flush, then 18 words (lanes 8..16), flush:
+            // the ring never holds more than 256 bytes of unflushed data.
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                emit(st.lo[i], base + 2 * i);
+                emit(st.hi[i], base + 2 * i + 1);
+            }
+            produced = min(base + 16, N);
+            __builtin_amdgcn_wave_barrier();
+            flush_ready();
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 8; i < 17; i++)
+            {
+                emit(st.lo[i], base + 2 * i);
+                emit(st.hi[i], base + 2 * i + 1);
+            }
+            produced = min(base + 34, N);
+            __builtin_amdgcn_wave_barrier();
+            flush_ready();
+            __builtin_amdgcn_wave_barrier();
+        }
+        // all lines are out; make them visible to this wave's own later loads/stores
+        __builtin_amdgcn_s_waitcnt(0);
+        __threadfence_block();
+
+        // ---- phase 2: candidate stream for the rejected coefficients ---------------------
+        uint32_t *mypoly = poly_base + (size_t)lane * poly_stride;
+        uint32_t k       = 0;          // rejected coefficients resolved so far
+        uint32_t scanpos = 0;          // overflow path: next index to scan for a marker
+        if (!active) nrej = 0;
+        while (__any(k < nrej))
+        {
+            KeccakState cs;
+            prng_absorb(cs, seed, ctr);
+            keccak_f1600(cs);
+            if (k < nrej)
+            {
+                ctr++;
+                uint32_t x = cs.lo[0];
+                if (x < bound)
+                {
+                    uint32_t pos;
+                    if (k < A.rej_cap)
+                    {
+                        pos     = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        scanpos = pos + 1;
+                    }
+                    else
+                    {
+                        // list overflow: rejected positions are exactly the marker words
+                        pos = scanpos;
+                        while (__hip_atomic_load(mypoly + pos, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT) != kRejMarker)
+                            pos++;
+                        scanpos = pos + 1;
+                    }
+                    mypoly[pos] = barrett32(x, q, crh);
+                    k++;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    if (A.ctr_out && active) A.ctr_out[b] = ctr;
+}
+
+// ------------------------------------------------------------------------------------------
+// Centered binomial error (k = 21): one 96-byte block -> 16 int8 coefficients per thread.
+// counter = ctr_base[b] (or 0) + ctr_offset + block index.  Output int8 [B][blocks*16].
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t byte_window(const uint32_t (&w)[24], int byte_off)
+{
+    // 32 bits starting at a compile-time byte offset of the 96-byte block
+    const int wi = byte_off >> 2, sh = (byte_off & 3) * 8;
+    if (sh == 0) return w[wi];
+    uint32_t hi = (wi + 1 < 24) ? w[wi + 1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, w[wi], sh);
+}
+
+__global__ __launch_bounds__(256) void k_sample_cbd(CbdArgs A)
+{
+    const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)A.B * A.blocks_per_ct;
+    if (gid >= total) return;
+    const size_t b   = gid / A.blocks_per_ct;
+    const uint32_t k = (uint32_t)(gid - b * A.blocks_per_ct);
+    uint32_t seed[16];
+    load_seed(seed, A.seeds, b);
+    uint64_t ctr = (A.ctr_base ? A.ctr_base[b] : 0) + k;
+    KeccakState st;
+    prng_absorb(st, seed, ctr);
+    keccak_f1600(st);
+    uint32_t w[24];
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+    {
+        w[2 * i]     = st.lo[i];
+        w[2 * i + 1] = st.hi[i];
+    }
+    // sample i = popcnt(bytes 6i,6i+1, low 5 bits of 6i+2) - popcnt(bytes 6i+3,6i+4, low 5 of 6i+5)
+    uint32_t packed[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        uint32_t pos = byte_window(w, 6 * i) & 0x001FFFFFu;
+        uint32_t neg = byte_window(w, 6 * i + 3) & 0x001FFFFFu;
+        int v        = __popc(pos) - __popc(neg);
+        packed[i >> 2] |= ((uint32_t)v & 0xFFu) << (8 * (i & 3));
+    }
+    *reinterpret_cast<uint4 *>(A.out + gid * 16) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Ternary u (asymmetric): lane per ciphertext.  Each iteration every lane runs ONE permutation
+// of whichever kind it needs next -- a 96-byte block, or a 1-byte redraw for the lowest pending
+// rejected byte of its current block (96-bit pending mask in 3 VGPRs) -- so lanes do not wait
+// for each other's rejection loops.  Output: one int8 code (0,1,2) per coefficient.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t mod3_u8(uint32_t r)
+{
+    // r < 256: r mod 3 via multiply-shift (exact for 8-bit inputs)
+    return r - 3u * ((r * 171u) >> 9);
+}
+
+__global__ __launch_bounds__(64) void k_sample_ternary(TernaryArgs A)
+{
+    const size_t b    = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool active = b < A.B;
+    const size_t bs   = active ? b : (size_t)A.B - 1;
+    const uint32_t n  = A.n;
+    const uint32_t nblocks = (n + 95) / 96;
+    uint32_t seed[16];
+    load_seed(seed, A.seeds, bs);
+    int8_t *out = A.codes + bs * n;
+
+    uint64_t ctr  = 0;
+    uint32_t blk  = 0;                 // next block to draw
+    uint32_t pend[3] = {0, 0, 0};      // pending rejected bytes of the current block
+    uint32_t cur_base = 0;             // first coefficient of the current block
+    bool done = !active;
+
+    while (__any(!done))
+    {
+        KeccakState st;
+        prng_absorb(st, seed, ctr);
+        keccak_f1600(st);
+        if (!done)
+        {
+            ctr++;
+            const bool redraw = (pend[0] | pend[1] | pend[2]) != 0;
+            if (redraw)
+            {
+                uint32_t r = st.lo[0] & 0xFFu;
+                if (r < 0xFEu)
+                {
+                    uint32_t pos;
+                    if (pend[0]) { pos = __builtin_ctz(pend[0]); pend[0] &= pend[0] - 1; }
+                    else if (pend[1]) { pos = 32 + __builtin_ctz(pend[1]); pend[1] &= pend[1] - 1; }
+                    else { pos = 64 + __builtin_ctz(pend[2]); pend[2] &= pend[2] - 1; }
+                    out[cur_base + pos] = (int8_t)mod3_u8(r);
+                }
+            }
+            else
+            {
+                cur_base            = blk * 96;
+                const uint32_t stop = min(96u, n - cur_base);
+                uint32_t w[24];
+#pragma unroll
+                for (int i = 0; i < 12; i++)
+                {
+                    w[2 * i]     = st.lo[i];
+                    w[2 * i + 1] = st.hi[i];
+                }
+#pragma unroll
+                for (int wi = 0; wi < 24; wi++)
+                {
+                    uint32_t codes = 0, rejbits = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        uint32_t r = (w[wi] >> (8 * k)) & 0xFFu;
+                        bool rej   = (r >= 0xFEu) && ((uint32_t)(4 * wi + k) < stop);
+                        rejbits |= (rej ? 1u : 0u) << k;
+                        codes |= mod3_u8(r) << (8 * k);
+                    }
+                    pend[wi >> 3] |= rejbits << (4 * (wi & 7));
+                    if ((uint32_t)(4 * wi) < stop)  // stop is a multiple of 4 (n is a power of two >= 1024)
+                        *reinterpret_cast<uint32_t *>(out + cur_base + 4 * wi) = codes;
+                }
+                blk++;
+            }
+            if (blk == nblocks && (pend[0] | pend[1] | pend[2]) == 0) done = true;
+        }
+    }
+    if (A.ctr_out && active) A.ctr_out[b] = ctr;
+}
+
+// Raw PRNG blocks for tests: out[i] = SHAKE256(seed[i] || le64(ctr[i]))[0 : outlen], lane per block.
+__global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs,
+                                                    uint8_t *out, uint32_t outlen, uint32_t count)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    uint32_t seed[16];
+    load_seed(seed, seeds, i);
+    KeccakState st;
+    prng_absorb(st, seed, ctrs[i]);
+    uint8_t *dst = out + i * outlen;
+    for (uint32_t off = 0; off < outlen; off += kShakeRate)
+    {
+        keccak_f1600(st);
+        uint32_t take = min((uint32_t)kShakeRate, outlen - off);
+        for (uint32_t by = 0; by < take; by++)
+        {
+            uint32_t lane64 = by >> 3, sh = (by & 7) * 8;
+            uint32_t word = 0;
+#pragma unroll
+            for (int l = 0; l < 17; l++)
+                if ((uint32_t)l == lane64) word = sh < 32 ? st.lo[l] >> sh : st.hi[l] >> (sh - 32);
+            dst[off + by] = (uint8_t)word;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A, hipStream_t st)
+{
+    if (A.B == 0) return hipSuccess;
+    dim3 grid((A.B + 63) / 64), block(64);
+    switch (P.logn)
+    {
+        case 10: hipLaunchKernelGGL(k_sample_uniform<10>, grid, block, 0, st, P, A); break;
+        case 11: hipLaunchKernelGGL(k_sample_uniform<11>, grid, block, 0, st, P, A); break;
+        case 12: hipLaunchKernelGGL(k_sample_uniform<12>, grid, block, 0, st, P, A); break;
+        case 13: hipLaunchKernelGGL(k_sample_uniform<13>, grid, block, 0, st, P, A); break;
+        case 14: hipLaunchKernelGGL(k_sample_uniform<14>, grid, block, 0, st, P, A); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_cbd(const CbdArgs &A, hipStream_t st)
+{
+    size_t total = (size_t)A.B * A.blocks_per_ct;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sample_cbd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
+{
+    if (A.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sample_ternary, dim3((A.B + 63) / 64), dim3(64), 0, st, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs, uint8_t *out,
+                              uint32_t outlen, uint32_t count, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prng_blocks, dim3((count + 63) / 64), dim3(64), 0, st, seeds, ctrs, out,
+                       outlen, count);
+    return hipGetLastError();
+}
+
+}  // namespace seamd

@@ -1,0 +1,197 @@
+// transform.cuh -- register-tiled radix-16 passes for the two length-n transforms of the path.
+//
+// One workgroup of n/16 threads owns one polynomial; every thread holds 16 points in VGPRs.
+// A "pass" runs up to four consecutive radix-2 stages entirely in registers; between passes the
+// points are re-dealt through LDS (one write + one read per point) instead of one LDS round trip
+// per stage.  n = 4096: 3 passes, 2 exchanges (instead of 12 barrier'd stages).
+//
+//   * inverse FFT of the CKKS encoder, FP64, DIF, rounds tt = 1,2,..,n/2, butterfly
+//     (u, v) -> (u + v, (u - v) * W[h + j])           /root/reference/device/lib/fft.c:69-144
+//   * forward negacyclic NTT, 32-bit residues, CT/Harvey, rounds h = 1,2,..,n/2, butterfly
+//     (u, v) -> (u + v*R[h + g], u - v*R[h + g])      /root/reference/device/lib/ntt.c:124-165
+//
+// Both index their root table with  (n >> (i+1)) + (k >> (i+1))  where i is the bit in which the
+// two butterfly inputs k, k + 2^i differ; the IFFT walks i upward, the NTT downward.
+//
+// Bit-exactness of the IFFT: every butterfly is the reference's, operand for operand --
+// complex product in C99 Annex-G order (ac - bd, ad + bc), each op individually rounded
+// (__dmul_rn/__dadd_rn/__dsub_rn are never contracted into FMAs).  Re-dealing points between
+// threads does not change any arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "modarith.cuh"
+
+namespace seamd {
+
+// compile-time loop: f(integral_constant<int, I>) for I in [BEGIN, END)
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (BEGIN < END)
+    {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+// Point index held in slot e (0..15) of thread t for a pass whose 16-point tiles span bits
+// [C, C+4) of the index.
+template <int C>
+__device__ __forceinline__ int tile_index(int t, int e)
+{
+    return ((t >> C) << (C + 4)) | (e << C) | (t & ((1 << C) - 1));
+}
+
+// LDS slot of point k: one pad element per 16 keeps every deal pattern used here (strides
+// 1, 2^C and 16) conflict-free for b32/b64 accesses ("LDS layout").
+__device__ __forceinline__ int lds_slot(int k)
+{
+    return k + (k >> 4);
+}
+
+template <int LOGN>
+struct XformGeom
+{
+    static constexpr int N       = 1 << LOGN;
+    static constexpr int THREADS = N / 16;
+    static constexpr int PASSES  = (LOGN + 3) / 4;
+    static constexpr int SLOTS   = N + N / 16;  // padded LDS elements
+    // window offset of pass p
+    static constexpr int ifft_c(int p) { return (4 * p < LOGN - 4) ? 4 * p : LOGN - 4; }
+    static constexpr int ntt_c(int p) { return (LOGN - 4 - 4 * p > 0) ? LOGN - 4 - 4 * p : 0; }
+};
+
+// Re-deal 16 values per thread from tile layout C_FROM to tile layout C_TO through `lds`.
+// Leaves the workgroup synchronised and `lds` free for reuse.
+template <int C_FROM, int C_TO, typename T>
+__device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
+{
+#pragma unroll
+    for (int e = 0; e < 16; e++) lds[lds_slot(tile_index<C_FROM>(t, e))] = v[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = lds[lds_slot(tile_index<C_TO>(t, e))];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// IFFT pass: stages for local bits [B_LO, B_HI) of a tile at window C, ascending.
+// ------------------------------------------------------------------------------------------
+template <int LOGN, int C, int B_LO, int B_HI>
+__device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
+                                          const double *__restrict__ W, int t)
+{
+    constexpr int N = 1 << LOGN;
+    const int thi   = t >> C;
+    static_for<B_LO, B_HI>([&](auto bc) {
+        constexpr int b      = decltype(bc)::value;
+        constexpr int h      = N >> (C + b + 1);
+        constexpr int groups = 1 << (3 - b);  // distinct twiddles this thread needs in this stage
+        static_for<0, groups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int idx   = h + ((thi << (3 - b)) | g);
+            const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
+            static_for<0, (1 << b)>([&](auto rc) {
+                constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
+                constexpr int e1 = e0 | (1 << b);
+                double ar = __dsub_rn(re[e0], re[e1]);
+                double ai = __dsub_rn(im[e0], im[e1]);
+                re[e0]    = __dadd_rn(re[e0], re[e1]);
+                im[e0]    = __dadd_rn(im[e0], im[e1]);
+                re[e1]    = __dsub_rn(__dmul_rn(ar, w.x), __dmul_rn(ai, w.y));
+                im[e1]    = __dadd_rn(__dmul_rn(ar, w.y), __dmul_rn(ai, w.x));
+            });
+        });
+    });
+}
+
+// Whole IFFT: input in tile layout 0 (thread t holds points 16t..16t+15), output in tile layout
+// LOGN-4 (thread t holds points t + (n/16)*e).  `plane` = LDS scratch of XformGeom::SLOTS doubles.
+template <int LOGN>
+__device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
+                                           const double *__restrict__ W, double *plane, int t)
+{
+    using G = XformGeom<LOGN>;
+    ifft_pass<LOGN, 0, 0, 4>(re, im, W, t);
+    redeal<0, 4>(re, plane, t);
+    redeal<0, 4>(im, plane, t);
+    ifft_pass<LOGN, 4, 0, 4>(re, im, W, t);
+    if constexpr (LOGN <= 12)
+    {
+        constexpr int C2 = G::ifft_c(2);  // 6, 7 or 8
+        redeal<4, C2>(re, plane, t);
+        redeal<4, C2>(im, plane, t);
+        ifft_pass<LOGN, C2, 8 - C2, 4>(re, im, W, t);
+    }
+    else
+    {
+        redeal<4, 8>(re, plane, t);
+        redeal<4, 8>(im, plane, t);
+        ifft_pass<LOGN, 8, 0, 4>(re, im, W, t);
+        constexpr int C3 = G::ifft_c(3);  // 9 or 10
+        redeal<8, C3>(re, plane, t);
+        redeal<8, C3>(im, plane, t);
+        ifft_pass<LOGN, C3, 12 - C3, 4>(re, im, W, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NTT pass: stages for local bits [B_LO, B_HI) of a tile at window C, descending.
+// RW = interleaved (root, shoup(root)) table of one prime.
+// ------------------------------------------------------------------------------------------
+template <int LOGN, int C, int B_LO, int B_HI>
+__device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
+                                         uint32_t q, uint32_t two_q, int t)
+{
+    constexpr int N = 1 << LOGN;
+    const int thi   = t >> C;
+    static_for<0, B_HI - B_LO>([&](auto sc) {
+        constexpr int b      = B_HI - 1 - decltype(sc)::value;  // descending
+        constexpr int h      = N >> (C + b + 1);
+        constexpr int groups = 1 << (3 - b);
+        static_for<0, groups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int idx   = h + ((thi << (3 - b)) | g);
+            const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
+            static_for<0, (1 << b)>([&](auto rc) {
+                constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
+                constexpr int e1 = e0 | (1 << b);
+                ct_butterfly(x[e0], x[e1], rw.x, rw.y, q, two_q);
+            });
+        });
+    });
+}
+
+// Whole NTT: input in tile layout LOGN-4 with values in [0, 2q] (anything < 4q), output in tile
+// layout 0 (thread t holds 16t..16t+15 of the bit-reversed-order result), values in [0,4q).
+template <int LOGN>
+__device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
+                                          uint32_t q, uint32_t *lds, int t)
+{
+    using G              = XformGeom<LOGN>;
+    const uint32_t two_q = q << 1;
+    constexpr int C0     = LOGN - 4;
+    ntt_pass<LOGN, C0, 0, 4>(x, RW, q, two_q, t);
+    constexpr int C1 = G::ntt_c(1);  // LOGN - 8
+    redeal<C0, C1>(x, lds, t);
+    ntt_pass<LOGN, C1, 0, 4>(x, RW, q, two_q, t);
+    if constexpr (LOGN <= 12)
+    {
+        redeal<C1, 0>(x, lds, t);
+        ntt_pass<LOGN, 0, 0, C1>(x, RW, q, two_q, t);  // remaining bits C1-1 .. 0
+    }
+    else
+    {
+        constexpr int C2 = G::ntt_c(2);  // LOGN - 12 (1 or 2)
+        redeal<C1, C2>(x, lds, t);
+        ntt_pass<LOGN, C2, 0, 4>(x, RW, q, two_q, t);
+        redeal<C2, 0>(x, lds, t);
+        ntt_pass<LOGN, 0, 0, C2>(x, RW, q, two_q, t);
+    }
+}
+
+}  // namespace seamd

@@ -1,0 +1,557 @@
+// se_api.cpp -- the extern "C" surface declared in include/seal_embedded_amd.h.
+//
+// Layer 1 mirrors /root/reference/device/lib/seal_embedded.c:24-235 (se_setup*, se_encrypt*,
+// se_cleanup) on top of the GPU context; layer 2 exposes the batched context API.
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/random.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/seal_embedded_amd.h"
+#include "se_context.h"
+
+namespace seamd {
+const std::string &last_error();
+}
+using seamd::Context;
+
+struct se_amd_ctx
+{
+    Context c;
+};
+
+static hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char *se_amd_last_error(void) { return seamd::last_error().c_str(); }
+const char *se_amd_version(void) { return "seal-embedded_amd 0.1 (gfx950)"; }
+
+int se_amd_create(se_amd_ctx **out, size_t degree, size_t nprimes, int device)
+{
+    if (!out) return SE_ERR_INVALD_ARGUMENT;
+    *out          = nullptr;
+    se_amd_ctx *h = new (std::nothrow) se_amd_ctx();
+    if (!h) return SE_ERR_NO_MEMORY;
+    int rc = h->c.init(degree, nprimes, device);
+    if (rc != 0)
+    {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SE_SUCCESS;
+}
+
+void se_amd_destroy(se_amd_ctx *ctx) { delete ctx; }
+
+size_t se_amd_degree(const se_amd_ctx *ctx) { return ctx ? ctx->c.hp.n : 0; }
+size_t se_amd_nprimes(const se_amd_ctx *ctx) { return ctx ? ctx->c.hp.nprimes : 0; }
+double se_amd_scale(const se_amd_ctx *ctx) { return ctx ? ctx->c.hp.scale : 0.0; }
+
+int se_amd_moduli(const se_amd_ctx *ctx, uint32_t *q)
+{
+    if (!ctx || !q) return SE_ERR_INVALD_ARGUMENT;
+    for (size_t j = 0; j < ctx->c.hp.nprimes; j++) q[j] = ctx->c.hp.q[j];
+    return SE_SUCCESS;
+}
+
+int se_amd_index_map(const se_amd_ctx *ctx, uint16_t *map)
+{
+    if (!ctx || !map) return SE_ERR_INVALD_ARGUMENT;
+    memcpy(map, ctx->c.index_map.data(), ctx->c.hp.n * sizeof(uint16_t));
+    return SE_SUCCESS;
+}
+
+int se_amd_set_secret_key(se_amd_ctx *ctx, const uint8_t *sk_packed)
+{
+    if (!ctx || !sk_packed) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.set_secret_key(sk_packed);
+}
+
+int se_amd_set_public_key(se_amd_ctx *ctx, const uint32_t *pk0, const uint32_t *pk1)
+{
+    if (!ctx || !pk0 || !pk1) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.set_public_key(pk0, pk1);
+}
+
+static int read_exact(const std::string &path, void *dst, size_t bytes)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+    {
+        seamd::set_last_error("cannot open key file " + path + ": " + strerror(errno));
+        return SE_ERR_INVALD_ARGUMENT;
+    }
+    size_t got = fread(dst, 1, bytes, f);
+    fclose(f);
+    if (got != bytes)
+    {
+        seamd::set_last_error("short read on key file " + path);
+        return SE_ERR_INVALD_ARGUMENT;
+    }
+    return SE_SUCCESS;
+}
+
+// File formats: fileops.c:140-204 (device side) / adapter/fileops.cpp:58-75,209-258 (writer side)
+int se_amd_load_keys_from_dir(se_amd_ctx *ctx, const char *dir, int want_pk)
+{
+    if (!ctx || !dir) return SE_ERR_INVALD_ARGUMENT;
+    const size_t n = ctx->c.hp.n, np = ctx->c.hp.nprimes;
+    char name[128];
+    if (!want_pk)
+    {
+        std::vector<uint8_t> sk(n / 4);
+        snprintf(name, sizeof(name), "/sk_%zu.dat", n);
+        int rc = read_exact(std::string(dir) + name, sk.data(), sk.size());
+        if (rc) return rc;
+        return ctx->c.set_secret_key(sk.data());
+    }
+    std::vector<uint32_t> pk0(np * n), pk1(np * n);
+    for (size_t j = 0; j < np; j++)
+    {
+        snprintf(name, sizeof(name), "/pk0_ntt_%zu_%u.dat", n, ctx->c.hp.q[j]);
+        int rc = read_exact(std::string(dir) + name, pk0.data() + j * n, n * 4);
+        if (rc) return rc;
+        snprintf(name, sizeof(name), "/pk1_ntt_%zu_%u.dat", n, ctx->c.hp.q[j]);
+        rc = read_exact(std::string(dir) + name, pk1.data() + j * n, n * 4);
+        if (rc) return rc;
+    }
+    return ctx->c.set_public_key(pk0.data(), pk1.data());
+}
+
+int se_amd_encrypt_sym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
+                              const uint8_t *d_share_seeds, const uint8_t *d_seeds, uint32_t *d_c0,
+                              uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte,
+                              uint8_t *d_status, void *stream)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.encrypt_sym(d_values, B, d_share_seeds, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte,
+                              d_status, as_stream(stream));
+}
+
+int se_amd_encrypt_asym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
+                               const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
+                               uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, void *stream)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.encrypt_asym(d_values, B, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte, d_status,
+                               as_stream(stream));
+}
+
+int se_amd_encode_ntt_device(se_amd_ctx *ctx, const float *d_values, size_t B, uint32_t *d_out,
+                             int64_t *d_pte, uint8_t *d_status, void *stream)
+{
+    if (!ctx || !d_out) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.encode_ntt(d_values, B, d_out, d_pte, d_status, as_stream(stream));
+}
+
+int se_amd_encode_device(se_amd_ctx *ctx, const float *d_values, size_t B, int64_t *d_out,
+                         uint8_t *d_status, void *stream)
+{
+    if (!ctx || !d_out || !d_values) return SE_ERR_INVALD_ARGUMENT;
+    if (B == 0) return SE_SUCCESS;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    seamd::EncArgs ea{d_values, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, d_status};
+    SEAMD_HIP(seamd::launch_encode_encrypt(ctx->c.dp, ctx->c.dt, ea, seamd::kModeEncodeOnly, B,
+                                           as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+int se_amd_ntt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t count, void *stream)
+{
+    if (!ctx || !d_polys || prime >= ctx->c.hp.nprimes) return SE_ERR_INVALD_ARGUMENT;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    SEAMD_HIP(seamd::launch_ntt_polys(ctx->c.dp, ctx->c.dt, (int)prime, d_polys, nullptr, count,
+                                      as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+int se_amd_prng_blocks_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctrs,
+                              uint8_t *d_out, size_t outlen, size_t count, void *stream)
+{
+    if (!ctx || !d_seeds || !d_ctrs || !d_out) return SE_ERR_INVALD_ARGUMENT;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    SEAMD_HIP(seamd::launch_prng_blocks(d_seeds, d_ctrs, d_out, (uint32_t)outlen, (uint32_t)count,
+                                        as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+int se_amd_sample_uniform_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctr_in,
+                                 size_t B, uint32_t *d_out, uint64_t *d_ctr_out, void *stream)
+{
+    if (!ctx || !d_seeds || !d_out) return SE_ERR_INVALD_ARGUMENT;
+    if (B == 0) return SE_SUCCESS;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_scratch(B);
+    if (rc) return rc;
+    const uint32_t np = (uint32_t)ctx->c.hp.nprimes;
+    seamd::UniformArgs ua{d_seeds, d_ctr_in, d_ctr_out, d_out, ctx->c.d_rej, ctx->c.rej_cap,
+                          (uint32_t)B, 0, np, np};
+    SEAMD_HIP(seamd::launch_sample_uniform(ctx->c.dp, ua, as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+int se_amd_sample_ternary_device(se_amd_ctx *ctx, const uint8_t *d_seeds, size_t B, int8_t *d_codes,
+                                 uint64_t *d_ctr_out, void *stream)
+{
+    if (!ctx || !d_seeds || !d_codes) return SE_ERR_INVALD_ARGUMENT;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    seamd::TernaryArgs ta{d_seeds, d_codes, d_ctr_out, (uint32_t)ctx->c.hp.n, (uint32_t)B};
+    SEAMD_HIP(seamd::launch_sample_ternary(ta, as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+int se_amd_sample_cbd_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctr_base,
+                             size_t B, size_t blocks_per_ct, int8_t *d_out, void *stream)
+{
+    if (!ctx || !d_seeds || !d_out) return SE_ERR_INVALD_ARGUMENT;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    seamd::CbdArgs ca{d_seeds, d_ctr_base, d_out, (uint32_t)blocks_per_ct, (uint32_t)B};
+    SEAMD_HIP(seamd::launch_sample_cbd(ca, as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+// sample.c:61-87: 2 bits per coefficient, first coefficient in the two MOST significant bits
+void se_amd_pack_ternary_host(const int8_t *codes, size_t n, uint8_t *packed)
+{
+    memset(packed, 0, n / 4);
+    for (size_t i = 0; i < n; i++)
+        packed[i / 4] |= (uint8_t)((codes[i] & 3) << (6 - 2 * (i % 4)));
+}
+
+int se_amd_set_profiling(se_amd_ctx *ctx, int enabled)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    ctx->c.profiling = enabled != 0;
+    return SE_SUCCESS;
+}
+
+int se_amd_stage_ms(se_amd_ctx *ctx, float *ms, uint64_t *launches, int reset)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    (void)hipSetDevice(ctx->c.device);
+    ctx->c.collect_events();
+    for (int i = 0; i < seamd::kStageCount; i++)
+    {
+        if (ms) ms[i] = ctx->c.stage_ms[i];
+        if (launches) launches[i] = ctx->c.stage_launches[i];
+        if (reset)
+        {
+            ctx->c.stage_ms[i]       = 0;
+            ctx->c.stage_launches[i] = 0;
+        }
+    }
+    return SE_SUCCESS;
+}
+
+int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    ctx->c.rej_cap     = cap;
+    ctx->c.scratch_cap = 0;  // force re-allocation with the new stride
+    return SE_SUCCESS;
+}
+
+int se_amd_reserve(se_amd_ctx *ctx, size_t B)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.ensure_scratch(B);
+}
+
+// ---- host-pointer wrappers ------------------------------------------------------------------
+namespace {
+struct DevBuf
+{
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 1;
+        hipError_t e = hipMalloc(&p, bytes);
+        return e == hipSuccess ? 0 : seamd::hip_fail(e, "hipMalloc(host wrapper)");
+    }
+};
+}  // namespace
+
+static int run_host(se_amd_ctx *ctx, bool asym, const float *values, size_t B,
+                    const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1,
+                    uint32_t *ntt_pte, int64_t *pte, uint8_t *status)
+{
+    if (!ctx || !values || !seeds || !c0 || !c1 || (!asym && !share_seeds))
+        return SE_ERR_INVALD_ARGUMENT;
+    if (B == 0) return SE_SUCCESS;
+    Context &c     = ctx->c;
+    const size_t n = c.hp.n, np = c.hp.nprimes;
+    SEAMD_HIP(hipSetDevice(c.device));
+    DevBuf dv, dss, dsd, d0, d1, dnp, dpt, dst;
+    int rc;
+    if ((rc = dv.alloc(B * (n / 2) * sizeof(float)))) return rc;
+    if ((rc = dsd.alloc(B * 64))) return rc;
+    if ((rc = d0.alloc(B * np * n * 4))) return rc;
+    if ((rc = d1.alloc(B * np * n * 4))) return rc;
+    if ((rc = dst.alloc(B))) return rc;
+    if (!asym && (rc = dss.alloc(B * 64))) return rc;
+    if (ntt_pte && (rc = dnp.alloc(B * np * n * 4))) return rc;
+    if (pte && (rc = dpt.alloc(B * n * 8))) return rc;
+    SEAMD_HIP(hipMemcpy(dv.p, values, B * (n / 2) * sizeof(float), hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(dsd.p, seeds, B * 64, hipMemcpyHostToDevice));
+    if (!asym) SEAMD_HIP(hipMemcpy(dss.p, share_seeds, B * 64, hipMemcpyHostToDevice));
+    if (asym)
+        rc = c.encrypt_asym((const float *)dv.p, B, (const uint8_t *)dsd.p, (uint32_t *)d0.p,
+                            (uint32_t *)d1.p, (uint32_t *)dnp.p, (int64_t *)dpt.p, (uint8_t *)dst.p,
+                            nullptr);
+    else
+        rc = c.encrypt_sym((const float *)dv.p, B, (const uint8_t *)dss.p, (const uint8_t *)dsd.p,
+                           (uint32_t *)d0.p, (uint32_t *)d1.p, (uint32_t *)dnp.p, (int64_t *)dpt.p,
+                           (uint8_t *)dst.p, nullptr);
+    if (rc) return rc;
+    SEAMD_HIP(hipDeviceSynchronize());
+    SEAMD_HIP(hipMemcpy(c0, d0.p, B * np * n * 4, hipMemcpyDeviceToHost));
+    SEAMD_HIP(hipMemcpy(c1, d1.p, B * np * n * 4, hipMemcpyDeviceToHost));
+    if (ntt_pte) SEAMD_HIP(hipMemcpy(ntt_pte, dnp.p, B * np * n * 4, hipMemcpyDeviceToHost));
+    if (pte) SEAMD_HIP(hipMemcpy(pte, dpt.p, B * n * 8, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> st(B);
+    SEAMD_HIP(hipMemcpy(st.data(), dst.p, B, hipMemcpyDeviceToHost));
+    int failed = 0;
+    for (size_t i = 0; i < B; i++) failed += st[i] ? 0 : 1;
+    if (status) memcpy(status, st.data(), B);
+    return failed;
+}
+
+int se_amd_encrypt_sym_host(se_amd_ctx *ctx, const float *values, size_t B,
+                            const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0,
+                            uint32_t *c1, uint32_t *ntt_pte, int64_t *pte, uint8_t *status)
+{
+    return run_host(ctx, false, values, B, share_seeds, seeds, c0, c1, ntt_pte, pte, status);
+}
+
+int se_amd_encrypt_asym_host(se_amd_ctx *ctx, const float *values, size_t B, const uint8_t *seeds,
+                             uint32_t *c0, uint32_t *c1, uint32_t *ntt_pte, int64_t *pte,
+                             uint8_t *status)
+{
+    return run_host(ctx, true, values, B, nullptr, seeds, c0, c1, ntt_pte, pte, status);
+}
+
+// =============================================================================================
+// Layer 1: the reference API.  Static singletons like seal_embedded.c:18-22 -- one parameter set
+// per process, not re-entrant.
+// =============================================================================================
+static Parms g_parms;
+static SE_PTRS g_ptrs;
+static SE_PARMS g_se_parms;
+static std::vector<Modulus> g_moduli;
+static std::vector<uint8_t> g_pool;
+static se_amd_ctx *g_ctx = nullptr;
+
+static const char *data_path()
+{
+    const char *p = getenv("SE_AMD_DATA_PATH");
+    return p ? p : "adapter_output_data";  // device/CMakeLists.txt:115,285
+}
+
+SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals, const ZZ *ratios,
+                          double scale, EncryptType encrypt_type)
+{
+    // Custom moduli are unreachable in the reference (ckks_setup_custom recurses, ckks_common.c:90);
+    // like se_setup, fall back to the default parameter set for (degree, nprimes).
+    (void)modulus_vals;
+    (void)ratios;
+    (void)scale;  // overwritten by the parameter set (parameters.c:190-226)
+    if (g_ctx)
+    {
+        se_amd_destroy(g_ctx);
+        g_ctx = nullptr;
+    }
+    int device     = getenv("SE_AMD_DEVICE") ? atoi(getenv("SE_AMD_DEVICE")) : 0;
+    int rc         = se_amd_create(&g_ctx, degree, nprimes, device);
+    if (rc != SE_SUCCESS)
+    {
+        // error convention of the reference: print and exit (ckks_sym.c:68-72, fileops.c:60-91)
+        fprintf(stderr, "Error! se_setup failed: %s\n", se_amd_last_error());
+        exit(1);
+    }
+    const bool asym = (encrypt_type == SE_ASYM_ENCR);
+    rc              = se_amd_load_keys_from_dir(g_ctx, data_path(), asym ? 1 : 0);
+    if (rc != SE_SUCCESS)
+    {
+        fprintf(stderr, "Error! %s\n", se_amd_last_error());
+        exit(1);
+    }
+    const Context &c = g_ctx->c;
+    const size_t n   = c.hp.n;
+    g_moduli.assign(nprimes, Modulus());
+    for (size_t j = 0; j < nprimes; j++)
+    {
+        g_moduli[j].value          = c.hp.q[j];
+        g_moduli[j].const_ratio[0] = c.hp.cr_lo[j];
+        g_moduli[j].const_ratio[1] = c.hp.cr_hi[j];
+    }
+    g_parms.coeff_count      = n;
+    g_parms.logn             = c.hp.logn;
+    g_parms.moduli           = g_moduli.data();
+    g_parms.curr_modulus     = g_moduli.data();
+    g_parms.curr_modulus_idx = 0;
+    g_parms.nprimes          = nprimes;
+    g_parms.scale            = c.hp.scale;
+    g_parms.is_asymmetric    = asym;
+    g_parms.pk_from_file     = 1;
+    g_parms.sample_s         = 0;
+    g_parms.small_u          = 1;
+    g_parms.small_s          = 1;
+
+    // host staging pool: conj_vals (16n) | values (2n) | c0 (4n) | c1 (4n) | index_map (2n)
+    // | ternary (n/4) | e1 (n).  The reference's aliasing plan (ckks_sym.c:29-160) is not
+    // reproduced; SE_PTRS fields stay valid for callers that inspect them.
+    g_pool.assign(16 * n + 2 * n + 4 * n + 4 * n + 2 * n + n / 4 + n + 64, 0);
+    uint8_t *p             = g_pool.data();
+    g_ptrs.conj_vals       = reinterpret_cast<double *>(p);
+    g_ptrs.conj_vals_int_ptr = reinterpret_cast<int64_t *>(p);
+    p += 16 * n;
+    g_ptrs.values = reinterpret_cast<flpt *>(p);
+    p += 2 * n;
+    g_ptrs.c0_ptr = reinterpret_cast<ZZ *>(p);
+    p += 4 * n;
+    g_ptrs.c1_ptr      = reinterpret_cast<ZZ *>(p);
+    g_ptrs.ntt_pte_ptr = g_ptrs.c1_ptr;  // same address as in the reference (ckks_sym.c:86-88)
+    p += 4 * n;
+    g_ptrs.index_map_ptr = reinterpret_cast<uint16_t *>(p);
+    memcpy(p, c.index_map.data(), 2 * n);
+    p += 2 * n;
+    g_ptrs.ternary = reinterpret_cast<ZZ *>(p);
+    p += n / 4;
+    g_ptrs.e1_ptr        = reinterpret_cast<int8_t *>(p);
+    g_ptrs.ifft_roots    = nullptr;
+    g_ptrs.ntt_roots_ptr = nullptr;
+    g_se_parms.parms     = &g_parms;
+    g_se_parms.se_ptrs   = &g_ptrs;
+    return &g_se_parms;
+}
+
+SE_PARMS *se_setup(size_t degree, size_t nprimes, double scale, EncryptType encrypt_type)
+{
+    return se_setup_custom(degree, nprimes, NULL, NULL, scale, encrypt_type);
+}
+
+SE_PARMS *se_setup_default(EncryptType encrypt_type)
+{
+    return se_setup(4096, 3, pow(2, 25), encrypt_type);  // seal_embedded.c:90-96
+}
+
+static void fill_seed(uint8_t *dst, const uint8_t *src)
+{
+    if (src)
+    {
+        memcpy(dst, src, SE_PRNG_SEED_BYTE_COUNT);
+        return;
+    }
+    ssize_t got = getrandom(dst, SE_PRNG_SEED_BYTE_COUNT, 0);  // rng.h:45-53
+    if (got != SE_PRNG_SEED_BYTE_COUNT)
+    {
+        fprintf(stderr, "Error! getrandom failed\n");
+        exit(1);
+    }
+}
+
+bool se_encrypt_seeded(uint8_t *shareable_seed, uint8_t *seed, SEND_FNCT_PTR network_send_function,
+                       void *v, size_t vlen_bytes, bool print, SE_PARMS *se_parms)
+{
+    if (!se_parms || !se_parms->parms || !se_parms->se_ptrs || !g_ctx) return false;
+    Parms *parms   = se_parms->parms;
+    SE_PTRS *ptrs  = se_parms->se_ptrs;
+    const size_t n = parms->coeff_count, np = parms->nprimes;
+
+    // seal_embedded.c:108-111: only the first copy_size bytes are cleared/overwritten, so a
+    // shorter input leaves the tail of a previous call in place (kept: "stale values" quirk).
+    size_t copy = (n / 2) * sizeof(ZZ);
+    if (vlen_bytes < copy) copy = vlen_bytes;
+    memset(ptrs->values, 0, copy);
+    memcpy(ptrs->values, v, copy);
+
+    uint8_t s_share[64], s_priv[64];
+    fill_seed(s_share, shareable_seed);
+    fill_seed(s_priv, seed);
+
+    std::vector<uint32_t> c0(np * n), c1(np * n), ntt_pte(np * n);
+    int rc;
+    if (parms->is_asymmetric)
+        rc = se_amd_encrypt_asym_host(g_ctx, ptrs->values, 1, s_priv, c0.data(), c1.data(),
+                                      ntt_pte.data(), ptrs->conj_vals_int_ptr, nullptr);
+    else
+        rc = se_amd_encrypt_sym_host(g_ctx, ptrs->values, 1, s_share, s_priv, c0.data(), c1.data(),
+                                     ntt_pte.data(), ptrs->conj_vals_int_ptr, nullptr);
+    if (rc < 0)
+    {
+        fprintf(stderr, "Error! se_encrypt: %s\n", se_amd_last_error());
+        exit(1);
+    }
+    if (rc > 0) return false;  // encode overflow (seal_embedded.c:115-118)
+
+    const char *quirk  = getenv("SE_AMD_REFERENCE_C1_ALIAS");
+    const bool alias   = !parms->is_asymmetric && quirk && quirk[0] == '1';
+    parms->curr_modulus_idx = 0;
+    for (size_t j = 0; j < np; j++)
+    {
+        parms->curr_modulus_idx = j;
+        parms->curr_modulus     = &parms->moduli[j];
+        memcpy(ptrs->c0_ptr, c0.data() + j * n, n * sizeof(ZZ));
+        memcpy(ptrs->c1_ptr, (alias ? ntt_pte.data() : c1.data()) + j * n, n * sizeof(ZZ));
+        if (print)
+        {
+            // text format of util_print.h:499-508: "name : { v0, v1, ... }"
+            const ZZ *polys[2]   = {ptrs->c0_ptr, ptrs->c1_ptr};
+            const char *names[2] = {"c0: ", "c1: "};
+            for (int k = 0; k < 2; k++)
+            {
+                printf("%s : { ", names[k]);
+                for (size_t i = 0; i < n; i++) printf(i + 1 < n ? "%u, " : "%u", polys[k][i]);
+                printf(" }\n");
+            }
+        }
+        if (network_send_function)
+        {
+            size_t nbytes = n * sizeof(ZZ);
+            if (network_send_function(ptrs->c0_ptr, nbytes) != nbytes) return false;
+            if (network_send_function(ptrs->c1_ptr, nbytes) != nbytes) return false;
+        }
+    }
+    return true;
+}
+
+bool se_encrypt(SEND_FNCT_PTR network_send_function, void *v, size_t vlen_bytes, bool print,
+                SE_PARMS *se_parms)
+{
+    return se_encrypt_seeded(NULL, NULL, network_send_function, v, vlen_bytes, print, se_parms);
+}
+
+void se_cleanup(SE_PARMS *se_parms)
+{
+    if (g_ctx)
+    {
+        se_amd_destroy(g_ctx);
+        g_ctx = nullptr;
+    }
+    g_pool.clear();
+    g_moduli.clear();
+    if (se_parms) se_parms->parms = 0;  // seal_embedded.c:234
+}
+
+int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
+                     const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1)
+{
+    if (!se_parms || !se_parms->parms || !g_ctx) return SE_ERR_INVALD_ARGUMENT;
+    if (se_parms->parms->is_asymmetric)
+        return se_amd_encrypt_asym_host(g_ctx, values, B, seeds, c0, c1, nullptr, nullptr, nullptr);
+    return se_amd_encrypt_sym_host(g_ctx, values, B, share_seeds, seeds, c0, c1, nullptr, nullptr,
+                                   nullptr);
+}
+
+}  // extern "C"

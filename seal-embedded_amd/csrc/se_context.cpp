@@ -1,0 +1,289 @@
+// se_context.cpp -- GPU context: table upload, key preparation, scratch, and the kernel chains of
+// the whole-path entry points.
+//
+// Kernel chains (all on the caller's stream, no host synchronisation inside):
+//   symmetric  (ckks_sym.c:181-301):  k_sample_cbd -> k_sample_uniform(a -> c1) -> k_encode_encrypt
+//   asymmetric (ckks_asym.c:173-286): k_sample_ternary(u, counter) -> k_sample_cbd(e0|e1 at
+//                                      counter base) -> k_encode_encrypt
+//   encode-only (BASELINE config 5):  k_encode_encrypt<EncodeOnly>
+#include "se_context.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace seamd {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error() { return g_last_error; }
+
+int hip_fail(hipError_t e, const char *what)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    set_last_error(buf);
+    return -1001;  // SE_ERR_HIP
+}
+
+Context::~Context()
+{
+    (void)hipSetDevice(device);
+    for (auto &ev : events)
+    {
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
+    }
+    void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1,
+                    d_err,     d_ucodes, d_ctr,    d_rej};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+int Context::init(size_t n, size_t nprimes, int dev)
+{
+    int rc = host_params_init(hp, n, nprimes);
+    if (rc != 0)
+    {
+        set_last_error("unsupported parameter set (degree, nprimes)");
+        return -22;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    {
+        set_last_error("no HIP device available: this library has no CPU path");
+        return -19;  // SE_ERR_NO_DEVICE
+    }
+    if (dev < 0 || dev >= count)
+    {
+        set_last_error("device index out of range");
+        return -22;
+    }
+    device = dev;
+    SEAMD_HIP(hipSetDevice(device));
+    dp = to_dev_params(hp);
+
+    std::vector<uint16_t> inv;
+    host_index_map(hp, index_map, inv);
+    std::vector<double> w;
+    host_ifft_twiddles(hp, w);
+    std::vector<uint32_t> rw_all(2 * n * nprimes), rw;
+    for (size_t j = 0; j < nprimes; j++)
+    {
+        host_ntt_root_pairs(hp, j, rw);
+        memcpy(rw_all.data() + 2 * n * j, rw.data(), 2 * n * sizeof(uint32_t));
+    }
+    SEAMD_HIP(hipMalloc((void **)&d_inv_map, n * sizeof(uint16_t)));
+    SEAMD_HIP(hipMalloc((void **)&d_ifft_w, 2 * n * sizeof(double)));
+    SEAMD_HIP(hipMalloc((void **)&d_ntt_rw, rw_all.size() * sizeof(uint32_t)));
+    SEAMD_HIP(hipMemcpy(d_inv_map, inv.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_ifft_w, w.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_ntt_rw, rw_all.data(), rw_all.size() * sizeof(uint32_t),
+                        hipMemcpyHostToDevice));
+    dt.inv_map = d_inv_map;
+    dt.ifft_w  = d_ifft_w;
+    dt.ntt_rw  = d_ntt_rw;
+    return 0;
+}
+
+int Context::ensure_scratch(size_t B)
+{
+    if (B <= scratch_cap) return 0;
+    SEAMD_HIP(hipSetDevice(device));
+    SEAMD_HIP(hipDeviceSynchronize());
+    void *old[] = {d_err, d_ucodes, d_ctr, d_rej};
+    for (void *p : old)
+        if (p) (void)hipFree(p);
+    d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_rej = nullptr;
+    scratch_cap    = 0;
+    const size_t n = hp.n;
+    SEAMD_HIP(hipMalloc((void **)&d_err, B * 2 * n));
+    SEAMD_HIP(hipMalloc((void **)&d_ucodes, B * n));
+    SEAMD_HIP(hipMalloc((void **)&d_ctr, B * sizeof(uint64_t)));
+    SEAMD_HIP(hipMalloc((void **)&d_rej, B * (size_t)(rej_cap ? rej_cap : 1) * sizeof(uint32_t)));
+    scratch_cap = B;
+    return 0;
+}
+
+// sk arrives 2-bit packed (sk_<n>.dat, fileops.c:140-170).  Expand per prime (sample.c:98-129),
+// NTT on the device, keep (NTT(s), shoup) pairs -- ckks_sym.c:255-266 hoisted out of the
+// per-ciphertext path.
+int Context::set_secret_key(const uint8_t *sk_packed)
+{
+    const size_t n = hp.n, np = hp.nprimes;
+    SEAMD_HIP(hipSetDevice(device));
+    std::vector<uint32_t> expanded(np * n);
+    for (size_t j = 0; j < np; j++)
+        for (size_t i = 0; i < n; i++)
+        {
+            uint32_t code = (sk_packed[i / 4] >> (6 - 2 * (i % 4))) & 3u;
+            if (code > 2)
+            {
+                set_last_error("secret key holds an invalid 2-bit code (3)");
+                return -22;
+            }
+            expanded[j * n + i] = code + (code == 0 ? hp.q[j] : 0u) - 1u;
+        }
+    uint32_t *d_tmp = nullptr;
+    SEAMD_HIP(hipMalloc((void **)&d_tmp, np * n * sizeof(uint32_t)));
+    if (!d_s_hat) SEAMD_HIP(hipMalloc((void **)&d_s_hat, 2 * np * n * sizeof(uint32_t)));
+    SEAMD_HIP(hipMemcpy(d_tmp, expanded.data(), np * n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (size_t j = 0; j < np; j++)
+        SEAMD_HIP(launch_ntt_polys(dp, dt, (int)j, d_tmp + j * n, d_s_hat + 2 * j * n, 1, nullptr));
+    SEAMD_HIP(hipDeviceSynchronize());
+    SEAMD_HIP(hipFree(d_tmp));
+    dt.s_hat = d_s_hat;
+    have_sk  = true;
+    return 0;
+}
+
+// pk slabs are already NTT-form residues (pk{0,1}_ntt_<n>_<q>.dat, fileops.c:172-204); add the
+// Shoup companions once.
+int Context::set_public_key(const uint32_t *pk0, const uint32_t *pk1)
+{
+    const size_t n = hp.n, np = hp.nprimes;
+    SEAMD_HIP(hipSetDevice(device));
+    for (size_t j = 0; j < np; j++)
+        for (size_t i = 0; i < n; i++)
+            if (pk0[j * n + i] >= hp.q[j] || pk1[j * n + i] >= hp.q[j])
+            {
+                set_last_error("public key coefficient not reduced modulo its prime");
+                return -22;
+            }
+    uint32_t *d_tmp = nullptr;
+    SEAMD_HIP(hipMalloc((void **)&d_tmp, 2 * np * n * sizeof(uint32_t)));
+    if (!d_pk0) SEAMD_HIP(hipMalloc((void **)&d_pk0, 2 * np * n * sizeof(uint32_t)));
+    if (!d_pk1) SEAMD_HIP(hipMalloc((void **)&d_pk1, 2 * np * n * sizeof(uint32_t)));
+    SEAMD_HIP(hipMemcpy(d_tmp, pk0, np * n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_tmp + np * n, pk1, np * n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (size_t j = 0; j < np; j++)
+    {
+        SEAMD_HIP(launch_make_pairs(d_tmp + j * n, d_pk0 + 2 * j * n, hp.q[j], n, nullptr));
+        SEAMD_HIP(launch_make_pairs(d_tmp + np * n + j * n, d_pk1 + 2 * j * n, hp.q[j], n, nullptr));
+    }
+    SEAMD_HIP(hipDeviceSynchronize());
+    SEAMD_HIP(hipFree(d_tmp));
+    dt.pk0  = d_pk0;
+    dt.pk1  = d_pk1;
+    have_pk = true;
+    return 0;
+}
+
+void Context::stage_begin(int stage, hipStream_t st)
+{
+    if (!profiling) return;
+    StageEvent ev;
+    ev.stage = stage;
+    (void)hipEventCreate(&ev.start);
+    (void)hipEventCreate(&ev.stop);
+    (void)hipEventRecord(ev.start, st);
+    events.push_back(ev);
+}
+
+void Context::stage_end(hipStream_t st)
+{
+    if (!profiling || events.empty()) return;
+    (void)hipEventRecord(events.back().stop, st);
+}
+
+void Context::collect_events()
+{
+    for (auto &ev : events)
+    {
+        float ms = 0;
+        if (hipEventSynchronize(ev.stop) == hipSuccess &&
+            hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess)
+        {
+            stage_ms[ev.stage] += ms;
+            stage_launches[ev.stage]++;
+        }
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
+    }
+    events.clear();
+}
+
+int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share_seeds,
+                         const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
+                         uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, hipStream_t st)
+{
+    if (!have_sk)
+    {
+        set_last_error("symmetric encryption needs a secret key (se_amd_set_secret_key)");
+        return -1002;
+    }
+    if (B == 0) return 0;
+    if (!d_values || !d_share_seeds || !d_seeds || !d_c0 || !d_c1) return -22;
+    SEAMD_HIP(hipSetDevice(device));
+    int rc = ensure_scratch(B);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
+
+    // e: n/16 CBD blocks per ciphertext from the secret seed, counters 0.. (ckks_sym.c:196)
+    CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
+    stage_begin(0, st);
+    SEAMD_HIP(launch_sample_cbd(ca, st));
+    stage_end(st);
+
+    // a_j for every prime from the shareable seed, written straight into c1 (ckks_sym.c:220)
+    UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np};
+    stage_begin(1, st);
+    SEAMD_HIP(launch_sample_uniform(dp, ua, st));
+    stage_end(st);
+
+    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
+    stage_begin(3, st);
+    SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
+    stage_end(st);
+    return 0;
+}
+
+int Context::encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
+                          uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
+                          hipStream_t st)
+{
+    if (!have_pk)
+    {
+        set_last_error("asymmetric encryption needs a public key (se_amd_set_public_key)");
+        return -1002;
+    }
+    if (B == 0) return 0;
+    if (!d_values || !d_seeds || !d_c0 || !d_c1) return -22;
+    SEAMD_HIP(hipSetDevice(device));
+    int rc = ensure_scratch(B);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)hp.n;
+
+    // u first: its redraws decide where the CBD counters start (ckks_asym.c:188-201)
+    TernaryArgs ta{d_seeds, d_ucodes, d_ctr, n, (uint32_t)B};
+    stage_begin(2, st);
+    SEAMD_HIP(launch_sample_ternary(ta, st));
+    stage_end(st);
+
+    // e0 (blocks 0..n/16-1) then e1 (blocks n/16..2n/16-1), contiguous per ciphertext
+    CbdArgs ca{d_seeds, d_ctr, d_err, 2 * (n / 16), (uint32_t)B};
+    stage_begin(0, st);
+    SEAMD_HIP(launch_sample_cbd(ca, st));
+    stage_end(st);
+
+    EncArgs ea{d_values, d_err, d_ucodes, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
+    stage_begin(3, st);
+    SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeAsym, B, st));
+    stage_end(st);
+    return 0;
+}
+
+int Context::encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_t *d_pte,
+                        uint8_t *d_status, hipStream_t st)
+{
+    if (B == 0) return 0;
+    if (!d_values || !d_out) return -22;
+    SEAMD_HIP(hipSetDevice(device));
+    EncArgs ea{d_values, nullptr, nullptr, d_out, nullptr, nullptr, d_pte, d_status};
+    stage_begin(3, st);
+    SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeEncodeOnly, B, st));
+    stage_end(st);
+    return 0;
+}
+
+}  // namespace seamd

@@ -1,0 +1,83 @@
+// se_context.h -- internal: the per-parameter-set GPU context behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels/kernel_args.h"
+#include "se_host_tables.h"
+#include "se_types.h"
+
+namespace seamd {
+
+constexpr int kStageCount = 4;
+
+struct StageEvent
+{
+    int stage;
+    hipEvent_t start, stop;
+};
+
+struct Context
+{
+    HostParams hp;
+    DevParams dp;
+    DevTables dt{};
+    int device = 0;
+    std::vector<uint16_t> index_map;  // host copy (SE_PTRS::index_map_ptr, tests)
+
+    // read-only device slabs
+    uint16_t *d_inv_map = nullptr;
+    double *d_ifft_w    = nullptr;
+    uint32_t *d_ntt_rw  = nullptr;
+    uint32_t *d_s_hat   = nullptr;
+    uint32_t *d_pk0     = nullptr;
+    uint32_t *d_pk1     = nullptr;
+    bool have_sk = false, have_pk = false;
+
+    // scratch, grown on demand
+    int8_t *d_err      = nullptr;  // [cap][2n]
+    int8_t *d_ucodes   = nullptr;  // [cap][n]
+    uint64_t *d_ctr    = nullptr;  // [cap]
+    uint32_t *d_rej    = nullptr;  // [cap][rej_cap]
+    size_t scratch_cap = 0;
+    uint32_t rej_cap   = 256;
+
+    // profiling
+    bool profiling = false;
+    std::vector<StageEvent> events;
+    float stage_ms[kStageCount]          = {0, 0, 0, 0};
+    uint64_t stage_launches[kStageCount] = {0, 0, 0, 0};
+
+    ~Context();
+    int init(size_t n, size_t nprimes, int device);
+    int ensure_scratch(size_t B);
+    int set_secret_key(const uint8_t *sk_packed);
+    int set_public_key(const uint32_t *pk0, const uint32_t *pk1);
+
+    int encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share_seeds,
+                    const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,
+                    int64_t *d_pte, uint8_t *d_status, hipStream_t st);
+    int encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
+                     uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
+                     hipStream_t st);
+    int encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_t *d_pte,
+                   uint8_t *d_status, hipStream_t st);
+
+    void stage_begin(int stage, hipStream_t st);
+    void stage_end(hipStream_t st);
+    void collect_events();
+};
+
+void set_last_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+}  // namespace seamd
+
+#define SEAMD_HIP(call)                                             \
+    do                                                              \
+    {                                                               \
+        hipError_t e__ = (call);                                    \
+        if (e__ != hipSuccess) return seamd::hip_fail(e__, #call);  \
+    } while (0)

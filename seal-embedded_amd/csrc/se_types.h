@@ -1,0 +1,43 @@
+// se_types.h -- plain-old-data shared by the host code and the gfx950 kernels.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace seamd {
+
+constexpr int kMaxPrimes  = 13;  // parameters.c:159-171
+constexpr int kSeedBytes  = 64;  // defines.h:67 (SE_PRNG_SEED_BYTE_COUNT)
+constexpr int kShakeRate  = 136;
+
+// Passed BY VALUE to every kernel (lands in SGPRs / kernarg).
+struct DevParams
+{
+    uint32_t n;
+    uint32_t logn;
+    uint32_t nprimes;
+    uint32_t q[kMaxPrimes];        // modulus chain
+    uint32_t cr_hi[kMaxPrimes];    // floor(2^64/q) >> 32  == floor(2^32/q)
+    uint32_t cr_lo[kMaxPrimes];    // floor(2^64/q) & 0xffffffff
+    uint32_t bound[kMaxPrimes];    // uniform rejection bound (sample.c:46)
+    double n_inv;                  // scale / n (ckks_common.c:183)
+};
+
+// Device-resident read-only tables (pointers into one HBM slab owned by the context).
+struct DevTables
+{
+    const uint16_t *inv_map;   // [n]   x[k] <- values[inv_map[k] & (n/2-1)]
+    const double *ifft_w;      // [n][2] (re, im) of W[t], t = h + j  (fft.c:129)
+    const uint32_t *ntt_rw;    // [np][n][2] (root, shoup(root)) indexed h + g (ntt.c:40-52)
+    const uint32_t *s_hat;     // [np][n][2] (NTT(s), shoup)       sym
+    const uint32_t *pk0;       // [np][n][2] (pk0, shoup)          asym
+    const uint32_t *pk1;       // [np][n][2] (pk1, shoup)          asym
+};
+
+enum Mode : int
+{
+    kModeSym        = 0,  // c1 = a, c0 = -a.s + NTT(m+e)
+    kModeAsym       = 1,  // c1 = pk1.u + NTT(e1), c0 = pk0.u + NTT(m+e0)
+    kModeEncodeOnly = 2,  // out = NTT(m mod q_j), no sampling (BASELINE config 5)
+};
+
+}  // namespace seamd

@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/seal_embedded_amd.h declares, and refuses to run without a GPU (no CPU fallback).
+No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    p = ge.load_package()
+    p.build_library()
+    return p
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "seal_embedded_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(se_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    names = declared_functions()
+    assert len(names) >= 30
+    for nm in names:
+        assert hasattr(L, nm), f"{nm} declared in include/seal_embedded_amd.h but not exported"
+    assert set(names) == set(pkg.EXPORTED_SYMBOLS)
+
+
+def test_header_cites_reference_interfaces():
+    text = open(os.path.join(ROOT, "include", "seal_embedded_amd.h")).read()
+    for cite in ("seal_embedded.h:91-130", "ckks_common.c:105-215", "ntt.c:168-189",
+                 "sample.c:39-57", "rng.h:78-91", "fileops.c:140-204"):
+        assert cite in text
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "seal_embedded_amd.h"\nint main(void){ SE_PARMS p; (void)p; return SE_SUCCESS; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o",
+                           str(tmp_path / "t.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c",
+                           str(src), "-o", str(tmp_path / "t2.o")])
+
+
+def test_reference_struct_layouts(pkg):
+    """Modulus / SE_PARMS layouts the reference's callers rely on (modulus.h:22-30,
+    seal_embedded.h:52-56)."""
+    class Modulus(C.Structure):
+        _fields_ = [("value", C.c_uint32), ("const_ratio", C.c_uint32 * 2)]
+    assert C.sizeof(Modulus) == 12
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.SealEmbeddedAmdError) as ei:
+        pkg.Context(4096, 3)
+    assert "no HIP device" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_product_does_not_touch_oracle():
+    """The oracle is test infrastructure: nothing under seal-embedded_amd/ may reference it."""
+    bad = []
+    pdir = os.path.join(ROOT, "seal-embedded_amd")
+    for dp, _, files in os.walk(pdir):
+        if "build" in dp.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".cuh", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"se_oracle|pyoracle|libse_ref|oracle/", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_pack_ternary_host_matches_reference_format(pkg):
+    import numpy as np
+    L = pkg.lib()
+    codes = np.array([0, 1, 2, 1, 2, 2, 0, 0], dtype=np.int8)
+    out = np.zeros(2, dtype=np.uint8)
+    L.se_amd_pack_ternary_host(codes.ctypes.data_as(C.c_void_p), 8, out.ctypes.data_as(C.c_void_p))
+    # MSB-first 2-bit fields (sample.c:61-87): 00 01 10 01 | 10 10 00 00
+    assert list(out) == [0b00011001, 0b10100000]

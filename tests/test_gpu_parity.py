@@ -1,0 +1,467 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE sizes -- through
+size-independent properties.  Bar: bit-exact (all outputs are integers / bytes).
+Nothing here reads /root/reference.
+"""
+import ctypes as C
+import hashlib
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import vectors as V
+
+pytestmark = pytest.mark.gpu
+
+SEED_A = hashlib.shake_256(b"golden-share").digest(64)
+SEED_B = hashlib.shake_256(b"golden-secret").digest(64)
+SEED_PK = hashlib.shake_256(b"golden-pk").digest(64)
+SEED_EP = hashlib.shake_256(b"golden-ep").digest(64)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from oracle import pyoracle
+    pyoracle.build(ref=False)
+    return dict(torch=torch, pkg=pkg, dev=torch.device("cuda:0"))
+
+
+def dev_t(env, a):
+    return env["torch"].from_numpy(np.ascontiguousarray(a)).to(env["dev"])
+
+
+def host_u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def seeds_np(B, tag):
+    return V.derive_seeds(tag, B)
+
+
+# --------------------------------------------------------------------------- PRNG / Keccak
+def test_prng_blocks_match_hashlib(env):
+    torch = env["torch"]
+    ctx = env["pkg"].Context(1024, 1)
+    cnt = 130
+    seeds = seeds_np(cnt, "prng-test")
+    ctrs = np.array([0, 1, 2 ** 32 - 1, 2 ** 32, 2 ** 63 + 5] + list(range(5, cnt)), dtype=np.uint64)
+    for outlen in (1, 4, 96, 136, 137, 300, 4096):
+        out = torch.zeros((cnt, outlen), dtype=torch.uint8, device=env["dev"])
+        ctx.prng_blocks(dev_t(env, seeds), dev_t(env, ctrs.view(np.int64)), out, outlen)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(cnt):
+            exp = hashlib.shake_256(seeds[i].tobytes() + struct.pack("<Q", int(ctrs[i]))).digest(outlen)
+            assert got[i].tobytes() == exp, (outlen, i)
+
+
+# --------------------------------------------------------------------------- samplers
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_sample_uniform_vs_oracle(env, shape):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    B = 70  # crosses a wave boundary (64) and leaves a ragged tail
+    ctx = env["pkg"].Context(n, npr)
+    o = Oracle(n, npr)
+    seeds = seeds_np(B, f"uni-{n}")
+    out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+    ctx.sample_uniform(dev_t(env, seeds), out, ctr_out=ctr_out)
+    torch.cuda.synchronize()
+    got, gctr = host_u32(out), ctr_out.cpu().numpy()
+    for b in range(B):
+        ctr = 0
+        for j in range(npr):
+            a, ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
+            assert (got[b, j] == a).all(), (b, j)
+        assert int(gctr[b]) == ctr
+
+
+def test_sample_uniform_golden_and_ctr_in(env, golden):
+    torch = env["torch"]
+    for (n, npr) in [(1024, 1), (4096, 3)]:
+        d = golden["digests"]["shapes"][f"{n}x{npr}"]["samplers"]
+        ctx = env["pkg"].Context(n, npr)
+        seeds = np.frombuffer(SEED_A, dtype=np.uint8).reshape(1, 64).copy()
+        out = torch.zeros((1, npr, n), dtype=torch.int32, device=env["dev"])
+        ctx.sample_uniform(dev_t(env, seeds), out)
+        torch.cuda.synchronize()
+        for j in range(npr):
+            assert V.sha256_hex(host_u32(out)[0, j]) == d[f"uniform_p{j}"]["sha256"]
+        # non-zero starting counter
+        from oracle.pyoracle import Oracle
+        o = Oracle(n, npr)
+        cin = np.array([12345678901], dtype=np.int64)
+        ctx.sample_uniform(dev_t(env, seeds), out, ctr_in=dev_t(env, cin))
+        torch.cuda.synchronize()
+        ctr = int(cin[0])
+        for j in range(npr):
+            a, ctr = o.sample_uniform(j, SEED_A, ctr)
+            assert (host_u32(out)[0, j] == a).all()
+
+
+def test_sample_uniform_reject_list_overflow_path(env):
+    """The rare branch (more rejections than list entries) forced by a tiny capacity: the
+    marker-rescan path must give the same polynomial (cdna guide rule 26)."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 66
+    o = Oracle(n, npr)
+    seeds = seeds_np(B, "uni-overflow")
+    exp = np.zeros((B, npr, n), dtype=np.uint32)
+    for b in range(B):
+        ctr = 0
+        for j in range(npr):
+            exp[b, j], ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
+    for cap in (0, 1, 7, 64):
+        ctx = env["pkg"].Context(n, npr)
+        ctx.set_reject_list_capacity(cap)
+        out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+        ctx.sample_uniform(dev_t(env, seeds), out)
+        torch.cuda.synchronize()
+        assert (host_u32(out) == exp).all(), cap
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 16384])
+def test_sample_ternary_and_cbd_vs_oracle(env, n):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    npr = 1 if n <= 2048 else 3
+    B = 67
+    ctx = env["pkg"].Context(n, npr)
+    o = Oracle(n, npr)
+    seeds = seeds_np(B, f"tern-{n}")
+    codes = torch.zeros((B, n), dtype=torch.int8, device=env["dev"])
+    ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+    ctx.sample_ternary(dev_t(env, seeds), codes, ctr_out)
+    err = torch.zeros((B, 2 * n), dtype=torch.int8, device=env["dev"])
+    ctx.sample_cbd(dev_t(env, seeds), err, 2 * (n // 16), ctr_base=ctr_out)
+    torch.cuda.synchronize()
+    gc, gctr, ge = codes.cpu().numpy(), ctr_out.cpu().numpy(), err.cpu().numpy()
+    for b in range(B):
+        u, c = o.sample_ternary_small(seeds[b].tobytes(), 0)
+        assert (ctx.pack_ternary(gc[b]) == u).all(), b
+        assert int(gctr[b]) == c
+        e0, c2 = o.cbd_int8(seeds[b].tobytes(), c)
+        e1, c3 = o.cbd_int8(seeds[b].tobytes(), c2)
+        assert (ge[b, :n] == e0).all() and (ge[b, n:] == e1).all(), b
+    # golden (compiled reference) for the fixed seed
+    # counter base NULL = 0
+    ctx.sample_cbd(dev_t(env, seeds), err[:, :n].contiguous(), n // 16)
+
+
+def test_sample_ternary_cbd_golden(env, golden):
+    torch = env["torch"]
+    for (n, npr) in [(1024, 1), (4096, 3), (16384, 6)]:
+        d = golden["digests"]["shapes"][f"{n}x{npr}"]["samplers"]
+        ctx = env["pkg"].Context(n, npr)
+        seeds = np.frombuffer(SEED_B, dtype=np.uint8).reshape(1, 64).copy()
+        codes = torch.zeros((1, n), dtype=torch.int8, device=env["dev"])
+        ctr_out = torch.zeros(1, dtype=torch.int64, device=env["dev"])
+        ctx.sample_ternary(dev_t(env, seeds), codes, ctr_out)
+        e = torch.zeros((1, n), dtype=torch.int8, device=env["dev"])
+        ctx.sample_cbd(dev_t(env, seeds), e, n // 16, ctr_base=ctr_out)
+        torch.cuda.synchronize()
+        assert int(ctr_out[0]) == d["ternary"]["ctr_out"]
+        assert V.sha256_hex(ctx.pack_ternary(codes.cpu().numpy()[0])) == d["ternary"]["sha256"]
+        assert V.sha256_hex(e.cpu().numpy()[0]) == d["cbd_int8"]["sha256"]
+
+
+# --------------------------------------------------------------------------- transforms
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_ntt_vs_oracle_and_golden(env, golden, shape):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    d = golden["digests"]["shapes"][f"{n}x{npr}"]
+    ctx = env["pkg"].Context(n, npr)
+    o = Oracle(n, npr)
+    rng = np.random.default_rng(d["ntt_random_seed"])
+    for j in range(npr):
+        q = o.q[j]
+        delta = np.zeros(n, dtype=np.uint32)
+        delta[1] = 1
+        ins = {"delta1": delta, "ones": np.ones(n, dtype=np.uint32),
+               "ramp": (np.arange(n, dtype=np.uint64) % q).astype(np.uint32),
+               "qm1": np.full(n, q - 1, dtype=np.uint32),
+               "random": rng.integers(0, q, n, dtype=np.uint64).astype(np.uint32)}
+        names = list(ins)
+        # extra: the non-canonical input q (reduce_pte_core edge) and a batch of randoms
+        extra = rng.integers(0, q, (5, n), dtype=np.uint64).astype(np.uint32)
+        extra[0, :8] = q
+        batch = np.concatenate([np.stack([ins[k] for k in names]), extra])
+        t = dev_t(env, batch.view(np.int32))
+        ctx.ntt(j, t)
+        torch.cuda.synchronize()
+        got = host_u32(t)
+        for i, name in enumerate(names):
+            assert V.sha256_hex(got[i]) == d["ntt"][f"{name}_p{j}"]["sha256"], (name, j)
+        for i in range(5):
+            assert (got[len(names) + i] == o.ntt(extra[i], j)).all()
+
+
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_encode_vs_oracle_and_golden(env, golden, shape):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    d = golden["digests"]["shapes"][f"{n}x{npr}"]["encode"]
+    ctx = env["pkg"].Context(n, npr)
+    o = Oracle(n, npr)
+    rng = np.random.default_rng(77 + n)
+    rows = [V.pattern_values(t, n) for t in range(9)]
+    rows.append(V.bench_values(1, n)[0])
+    rows.append(np.full(n // 2, 3.0e38, dtype=np.float32))                 # overflow -> status 0
+    rows.append((rng.standard_normal(n // 2) * 1e6).astype(np.float32))    # large magnitudes
+    rows.append((rng.standard_normal(n // 2) * 1e-3).astype(np.float32))   # tiny magnitudes
+    big = np.zeros(n // 2, dtype=np.float32)
+    big[0] = 2.0 ** 40                                                     # near the int64 edge
+    rows.append(big)
+    vals = np.stack(rows)
+    out = torch.zeros((vals.shape[0], n), dtype=torch.int64, device=env["dev"])
+    status = torch.zeros(vals.shape[0], dtype=torch.uint8, device=env["dev"])
+    ctx.encode(dev_t(env, vals), out, status)
+    torch.cuda.synchronize()
+    got, st = out.cpu().numpy(), status.cpu().numpy()
+    for t in range(9):
+        assert st[t] == 1 and V.sha256_hex(got[t]) == d[f"pattern{t}"]["sha256"], t
+    assert V.sha256_hex(got[9]) == d["bench0"]["sha256"]
+    assert st[10] == 0 and d["overflow_3e38_ok"] is False
+    for i in (11, 12, 13):
+        ok, m = o.encode(vals[i])
+        assert bool(st[i]) == ok
+        if ok:
+            assert (got[i] == m).all(), i
+
+
+# --------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_encrypt_sym_vs_oracle(env, golden, shape):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    B = 9 if n >= 8192 else 67
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n)
+    vals[0] = V.survey_values(n)
+    ss, sd = V.bench_seeds(B)
+    ss[0] = np.frombuffer(V.SURVEY_SHARE_SEED, dtype=np.uint8)
+    sd[0] = np.frombuffer(V.SURVEY_SEED, dtype=np.uint8)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    ntt_pte = torch.zeros_like(c0)
+    pte = torch.zeros((B, n), dtype=torch.int64, device=env["dev"])
+    status = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, ntt_pte, pte, status)
+    torch.cuda.synchronize()
+    g0, g1, gp, gm = host_u32(c0), host_u32(c1), host_u32(ntt_pte), pte.cpu().numpy()
+    assert status.cpu().numpy().all()
+    for b in range(B):
+        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (gm[b] == r["pte"]).all(), ("pte", b)
+        assert (g1[b] == r["c1"]).all(), ("c1", b)
+        assert (gp[b] == r["ntt_pte"]).all(), ("ntt_pte", b)
+        assert (g0[b] == r["c0"]).all(), ("c0", b)
+    g = golden["digests"]["shapes"][f"{n}x{npr}"]["sym_survey"]
+    assert V.sha256_hex(g0[0]) == g["c0_sha256"] and V.sha256_hex(g1[0]) == g["c1_sha256"]
+    assert V.sha256_hex(gm[0]) == g["pte_sha256"]
+    assert V.sha256_hex(gp[0]) == g["c1_alias_sha256"]
+
+
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_encrypt_asym_vs_oracle(env, golden, shape):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    B = 5 if n >= 8192 else 66
+    o = Oracle(n, npr)
+    sk = V.secret_key(n)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    g = golden["digests"]["shapes"][f"{n}x{npr}"]["asym_survey"]
+    assert V.sha256_hex(pk0) == g["pk0_sha256"]
+    ctx = env["pkg"].Context(n, npr)
+    ctx.set_public_key(pk0, pk1)
+    vals = V.bench_values(B, n)
+    vals[0] = V.survey_values(n)
+    _, sd = V.bench_seeds(B)
+    sd[0] = np.frombuffer(V.SURVEY_SEED, dtype=np.uint8)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    pte = torch.zeros((B, n), dtype=torch.int64, device=env["dev"])
+    ctx.encrypt_asym(dev_t(env, vals), dev_t(env, sd), c0, c1, pte=pte)
+    torch.cuda.synchronize()
+    g0, g1, gm = host_u32(c0), host_u32(c1), pte.cpu().numpy()
+    for b in range(B):
+        r = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+        assert (gm[b] == r["pte"]).all(), ("pte", b)
+        assert (g1[b] == r["c1"]).all(), ("c1", b)
+        assert (g0[b] == r["c0"]).all(), ("c0", b)
+    assert V.sha256_hex(g0[0]) == g["c0_sha256"] and V.sha256_hex(g1[0]) == g["c1_sha256"]
+
+
+def test_encode_only_config5(env):
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 33
+    ctx = env["pkg"].Context(n, npr)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n, first=1000)
+    out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    ctx.encode_ntt(dev_t(env, vals), out)
+    torch.cuda.synchronize()
+    got = host_u32(out)
+    for b in range(B):
+        ok, m = o.encode(vals[b])
+        for j in range(npr):
+            assert (got[b, j] == o.ntt(o.reduce_pte(m, j), j)).all()
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 129])
+def test_ragged_batch_sizes(env, B):
+    from oracle.pyoracle import Oracle
+    n, npr = 1024, 1
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=5)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n, first=7)
+    ss, sd = V.bench_seeds(B, first=7)
+    r = ctx.encrypt_sym_host(vals, ss, sd)
+    assert r["failed"] == 0
+    for b in sorted({0, B // 2, B - 1}):
+        e = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (r["c0"][b] == e["c0"]).all() and (r["c1"][b] == e["c1"]).all()
+
+
+def test_empty_batch_and_missing_key(env):
+    pkg = env["pkg"]
+    ctx = pkg.Context(1024, 1)
+    with pytest.raises(pkg.SealEmbeddedAmdError):
+        ctx.encrypt_sym_host(V.bench_values(1, 1024), *V.bench_seeds(1))   # no key set
+    ctx.set_secret_key(V.secret_key(1024))
+    r = ctx.encrypt_sym_host(np.zeros((0, 512), dtype=np.float32), np.zeros((0, 64), np.uint8),
+                             np.zeros((0, 64), np.uint8))
+    assert r["failed"] == 0 and r["c0"].shape[0] == 0
+    with pytest.raises(pkg.SealEmbeddedAmdError):
+        pkg.Context(1000, 1)            # unsupported degree
+    with pytest.raises(pkg.SealEmbeddedAmdError):
+        pkg.Context(4096, 4)            # too many primes for n=4096 (parameters.c:212)
+
+
+def test_overflow_reports_failed_plaintexts(env):
+    n = 1024
+    ctx = env["pkg"].Context(n, 1)
+    ctx.set_secret_key(V.secret_key(n))
+    vals = V.bench_values(3, n)
+    vals[1, :] = 3.0e38
+    r = ctx.encrypt_sym_host(vals, *V.bench_seeds(3))
+    assert r["failed"] == 1 and list(r["status"]) == [1, 0, 1]
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_config2(env):
+    """BASELINE config 2 shape (n=4096, 3 primes) at a large batch: (a) the reference's own
+    round-trip criterion c0 + c1*NTT(s) == NTT(m+e) exactly (ckks_tests_common.c:206) evaluated
+    on the GPU outputs for EVERY ciphertext; (b) oracle spot checks on scattered records;
+    (c) determinism: a second run gives identical bytes."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = 4096, 3
+    B = int(os.environ.get("SE_TEST_FULL_B", "16384"))
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n)
+    ss, sd = V.bench_seeds(B)
+    dv, dss, dsd = dev_t(env, vals), dev_t(env, ss), dev_t(env, sd)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    ntt_pte = torch.zeros_like(c0)
+    status = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encrypt_sym(dv, dss, dsd, c0, c1, ntt_pte, None, status)
+    torch.cuda.synchronize()
+    assert bool(status.all())
+    for j in range(npr):
+        q = o.q[j]
+        s_hat = dev_t(env, o.ntt(o.expand_ternary(sk, j), j).astype(np.int64))
+        a = c1[:, j, :].to(torch.int64)
+        lhs = (c0[:, j, :].to(torch.int64) + (a * s_hat) % q) % q
+        assert bool((lhs == ntt_pte[:, j, :].to(torch.int64)).all()), j
+        assert int(c0[:, j, :].max()) < q and int(c0[:, j, :].min()) >= 0
+        assert int(c1[:, j, :].max()) < q and int(c1[:, j, :].min()) >= 0
+    for b in (0, 1, 63, 64, B // 2 + 17, B - 1):
+        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b
+    d0 = torch.zeros_like(c0)
+    d1 = torch.zeros_like(c0)
+    ctx.encrypt_sym(dv, dss, dsd, d0, d1)
+    torch.cuda.synchronize()
+    assert bool((d0 == c0).all()) and bool((d1 == c1).all())
+
+
+# --------------------------------------------------------------------------- reference API layer
+def test_reference_api_callback_stream(env, golden, tmp_path):
+    """se_setup / se_encrypt_seeded through the drop-in symbols: 2*np callbacks of 4n bytes, c0
+    then c1 per prime; with SE_AMD_REFERENCE_C1_ALIAS=1 the byte stream equals the compiled
+    reference's (FNV digest in the golden file), without it c1 is the true `a`."""
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    L = env["pkg"].lib()
+    n, npr = 4096, 3
+    d = golden["digests"]["shapes"][f"{n}x{npr}"]
+    data = tmp_path / "adapter_output_data"
+    data.mkdir()
+    sk = V.secret_key(n)
+    sk.tofile(data / f"sk_{n}.dat")
+    os.environ["SE_AMD_DATA_PATH"] = str(data)
+
+    class SE_PARMS(C.Structure):
+        _fields_ = [("parms", C.c_void_p), ("se_ptrs", C.c_void_p)]
+
+    SEND = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_size_t)
+    L.se_setup.restype = C.POINTER(SE_PARMS)
+    L.se_setup.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_int]
+    L.se_encrypt_seeded.restype = C.c_bool
+    L.se_encrypt_seeded.argtypes = [C.c_void_p, C.c_void_p, SEND, C.c_void_p, C.c_size_t,
+                                    C.c_bool, C.POINTER(SE_PARMS)]
+    L.se_cleanup.argtypes = [C.POINTER(SE_PARMS)]
+    chunks = []
+
+    def cb(ptr, nbytes):
+        chunks.append(C.string_at(ptr, nbytes))
+        return nbytes
+
+    vals = V.survey_values(n)
+    s1 = (C.c_uint8 * 64).from_buffer_copy(V.SURVEY_SHARE_SEED)
+    s2 = (C.c_uint8 * 64).from_buffer_copy(V.SURVEY_SEED)
+    o = Oracle(n, npr)
+    exp = o.encrypt_sym(vals, V.SURVEY_SHARE_SEED, V.SURVEY_SEED, sk)
+    try:
+        for alias in ("1", "0"):
+            os.environ["SE_AMD_REFERENCE_C1_ALIAS"] = alias
+            sp = L.se_setup(n, npr, 0.0, 0)
+            chunks.clear()
+            ok = L.se_encrypt_seeded(s1, s2, SEND(cb), vals.ctypes.data, vals.nbytes, False, sp)
+            assert ok and len(chunks) == 2 * npr and all(len(c) == 4 * n for c in chunks)
+            stream = b"".join(chunks)
+            if alias == "1":
+                assert "%016x" % pyoracle.fnv1a64(stream) == d["api_fnv1a64_sym"]
+            else:
+                want = b"".join(exp["c0"][j].tobytes() + exp["c1"][j].tobytes() for j in range(npr))
+                assert stream == want
+            L.se_cleanup(sp)
+    finally:
+        os.environ.pop("SE_AMD_REFERENCE_C1_ALIAS", None)
+        os.environ.pop("SE_AMD_DATA_PATH", None)
