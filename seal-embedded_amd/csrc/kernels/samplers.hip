@@ -39,123 +39,90 @@ __device__ __forceinline__ void load_seed(uint32_t (&seed)[16], const uint8_t *s
 }
 
 // ------------------------------------------------------------------------------------------
-// Uniform `a` for all primes of one ciphertext per lane.
+// Uniform `a` for all primes of one ciphertext per lane (the chain of counters is sequential per
+// ciphertext: prime j+1 starts where prime j's redraws stopped).
 //
-// Output coalescing: a lane produces 136 contiguous bytes of ITS polynomial per permutation, 64
-// lanes write to 64 different polynomials.  Words go to a 256-byte per-lane LDS ring; whenever a
-// 128-byte line of the output is complete the wave stores it cooperatively (8 lanes x 16 B per
-// line, 8 lines per instruction), so HBM sees full 128-byte lines.
-// Rejected positions are recorded in a per-ciphertext list in HBM scratch (REJ_CAP entries) and
-// patched in phase 2; beyond REJ_CAP the lane rescans its own output for the marker word.
+// Phase 1 (bulk block): 4n bytes are squeezed 136 at a time; each 32-bit word is reduced mod q
+// in registers (or replaced by a marker when it fails the rejection bound) and stored straight
+// to the lane's own polynomial as 8-byte pieces.  64 lanes write 64 different polynomials, so a
+// store instruction touches 64 lines -- but every lane completes a 128-byte line within about
+// one permutation, the partially written lines sit in L2 (64 x 128 B per wave) and reach HBM
+// as full lines.  (A cooperative LDS-transposed store was measured slower: +3x on the bulk step.)
+// Phase 2 (redraws): the k-th rejected coefficient takes the k-th accepted candidate of the
+// stream block(ctr+1)[0:4], block(ctr+2)[0:4], ...; all lanes draw in lock step until every
+// lane of the wave is done.  Rejected positions live in a per-ciphertext list in HBM scratch
+// (rej_cap entries); beyond that the lane rescans its own output for the marker word.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid residue
-
 
 template <int LOGN>
 __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs A)
 {
-    constexpr int N           = 1 << LOGN;
-    constexpr int LINES       = N * 4 / 128;             // 128-byte lines per polynomial
-    constexpr int STEPS       = (N * 4 + 135) / 136;     // permutations of the bulk block
-    constexpr int RING_WORDS  = 64;                      // 256 B per lane
-    __shared__ __attribute__((aligned(16))) uint32_t ring[64 * RING_WORDS];
+    constexpr int N          = 1 << LOGN;
+    constexpr int FULL_STEPS = (N * 4) / 136;            // permutations that yield 34 words
+    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;      // words taken from one more permutation
 
-    const int lane     = threadIdx.x;
-    const size_t b0    = (size_t)blockIdx.x * 64;
-    const size_t b     = b0 + lane;
-    const bool active  = b < A.B;
-    const size_t bsafe = active ? b : (size_t)A.B - 1;
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
 
     uint32_t seed[16];
-    load_seed(seed, A.seeds, bsafe);
-    uint64_t ctr = A.ctr_in ? A.ctr_in[bsafe] : 0;
-    uint32_t *myring = ring + lane * RING_WORDS;
-    uint32_t *mylist = A.rej_list + bsafe * A.rej_cap;
+    load_seed(seed, A.seeds, b);
+    uint64_t ctr     = A.ctr_in ? A.ctr_in[b] : 0;
+    uint32_t *mylist = A.rej_list + b * A.rej_cap;
 
     for (uint32_t j = A.prime_lo; j < A.prime_hi; j++)
     {
         const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
-        uint32_t *poly_base = A.out + (b0 * A.out_primes + j) * (size_t)N;  // lane 0's polynomial
-        const size_t poly_stride = (size_t)A.out_primes * N;                // between lanes
+        uint32_t *mypoly = A.out + (b * A.out_primes + j) * (size_t)N;
 
         KeccakState st;
         prng_absorb(st, seed, ctr);
         ctr++;
         uint32_t nrej = 0;
-        int produced  = 0;  // words written to the ring so far (uniform across lanes)
-        int flushed   = 0;  // lines stored so far
 
-        auto emit = [&](uint32_t x, int widx) {
-            // widx = coefficient index (uniform).  Reject test and reduction: sample.c:50-56
-            bool rej = x >= bound;
+        // reject test and reduction of one word: sample.c:50-56
+        auto word = [&](uint32_t x, uint32_t idx) -> uint32_t {
             uint32_t r = barrett32(x, q, crh);
-            if (widx < N)
+            if (x >= bound)
             {
-                if (rej)
-                {
-                    if (nrej < A.rej_cap) mylist[nrej] = (uint32_t)widx;
-                    nrej++;
-                }
-                myring[widx & (RING_WORDS - 1)] = rej ? kRejMarker : r;
+                if (nrej < A.rej_cap) mylist[nrej] = idx;
+                nrej++;
+                r = kRejMarker;
             }
-        };
-        auto flush_ready = [&]() {
-            // store every complete, not yet stored line (at most one per call by construction)
-            while ((flushed + 1) * 32 <= produced && flushed < LINES)
-            {
-                const int ring_off = (flushed & 1) * 32;  // words
-#pragma unroll
-                for (int it = 0; it < 8; it++)
-                {
-                    const int src = (lane >> 3) + 8 * it;          // which lane's polynomial
-                    const int seg = lane & 7;                      // 16-byte segment of the line
-                    uint4 v = *reinterpret_cast<const uint4 *>(ring + src * RING_WORDS + ring_off + 4 * seg);
-                    if (b0 + src < A.B)
-                    {
-                        uint32_t *dst = poly_base + src * poly_stride + flushed * 32 + 4 * seg;
-                        *reinterpret_cast<uint4 *>(dst) = v;
-                    }
-                }
-                flushed++;
-            }
+            return r;
         };
 
-        for (int step = 0; step < STEPS; step++)
+        uint32_t idx = 0;
+        for (int step = 0; step < FULL_STEPS; step++)
         {
             keccak_f1600(st);
-            const int base = step * 34;
-            // first 16 words (state lanes 0..7), flush, then 18 words (lanes 8..16), flush:
-            // the ring never holds more than 256 bytes of unflushed data.
 #pragma unroll
-            for (int i = 0; i < 8; i++)
+            for (int i = 0; i < 17; i++)
             {
-                emit(st.lo[i], base + 2 * i);
-                emit(st.hi[i], base + 2 * i + 1);
+                uint32_t w0 = word(st.lo[i], idx + 2 * i);
+                uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
+                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
             }
-            produced = min(base + 16, N);
-            __builtin_amdgcn_wave_barrier();
-            flush_ready();
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 8; i < 17; i++)
-            {
-                emit(st.lo[i], base + 2 * i);
-                emit(st.hi[i], base + 2 * i + 1);
-            }
-            produced = min(base + 34, N);
-            __builtin_amdgcn_wave_barrier();
-            flush_ready();
-            __builtin_amdgcn_wave_barrier();
+            idx += 34;
         }
-        // all lines are out; make them visible to this wave's own later loads/stores
+        if constexpr (TAIL_WORDS > 0)
+        {
+            keccak_f1600(st);
+#pragma unroll
+            for (int i = 0; i < TAIL_WORDS / 2; i++)
+            {
+                uint32_t w0 = word(st.lo[i], idx + 2 * i);
+                uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
+                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+            }
+        }
+        // bulk stores (and list entries) must have landed before phase 2 patches / reads them
         __builtin_amdgcn_s_waitcnt(0);
         __threadfence_block();
 
         // ---- phase 2: candidate stream for the rejected coefficients ---------------------
-        uint32_t *mypoly = poly_base + (size_t)lane * poly_stride;
-        uint32_t k       = 0;          // rejected coefficients resolved so far
-        uint32_t scanpos = 0;          // overflow path: next index to scan for a marker
-        if (!active) nrej = 0;
+        uint32_t k       = 0;  // rejected coefficients resolved so far
+        uint32_t scanpos = 0;  // overflow path: next index to scan for a marker
         while (__any(k < nrej))
         {
             KeccakState cs;
@@ -170,8 +137,7 @@ __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs 
                     uint32_t pos;
                     if (k < A.rej_cap)
                     {
-                        pos     = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        scanpos = pos + 1;
+                        pos = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     else
                     {
@@ -180,8 +146,8 @@ __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs 
                         while (__hip_atomic_load(mypoly + pos, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT) != kRejMarker)
                             pos++;
-                        scanpos = pos + 1;
                     }
+                    scanpos     = pos + 1;
                     mypoly[pos] = barrett32(x, q, crh);
                     k++;
                 }
@@ -189,7 +155,7 @@ __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs 
         }
         __builtin_amdgcn_s_waitcnt(0);
     }
-    if (A.ctr_out && active) A.ctr_out[b] = ctr;
+    if (A.ctr_out) A.ctr_out[b] = ctr;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ int Context::init(size_t n, size_t nprimes, int dev)
     device = dev;
     SEAMD_HIP(hipSetDevice(device));
     dp = to_dev_params(hp);
+    rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);  // >= 3x the expected rejections per polynomial
 
     std::vector<uint16_t> inv;
     host_index_map(hp, index_map, inv);
