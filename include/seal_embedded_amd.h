@@ -218,6 +218,8 @@ int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
 /* Pre-allocate the internal scratch for batches of up to B plaintexts (keeps hipMalloc out of
  * the first timed call). */
 int se_amd_reserve(se_amd_ctx *ctx, size_t B);
+/* timing ablations of the uniform sampler (tools/ablate.py); outputs are WRONG when non-zero. */
+int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags);
 const char *se_amd_last_error(void);
 const char *se_amd_version(void);
 

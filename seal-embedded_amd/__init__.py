@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
     "se_amd_pack_ternary_host", "se_amd_set_profiling", "se_amd_stage_ms",
-    "se_amd_set_reject_list_capacity", "se_amd_reserve", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -96,6 +96,7 @@ def lib():
     L.se_amd_stage_ms.argtypes = [vp, vp, vp, i32]
     L.se_amd_set_reject_list_capacity.argtypes = [vp, u32]
     L.se_amd_reserve.argtypes = [vp, sz]
+    L.se_amd_set_debug_flags.argtypes = [vp, u32]
     _lib = L
     return L
 
@@ -275,6 +276,9 @@ class Context:
         cnt = (C.c_uint64 * len(STAGES))()
         _check(self.L.se_amd_stage_ms(self.h, ms, cnt, 1 if reset else 0), "se_amd_stage_ms")
         return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(STAGES)}
+
+    def set_debug_flags(self, flags):
+        _check(self.L.se_amd_set_debug_flags(self.h, flags), "se_amd_set_debug_flags")
 
     def reserve(self, B):
         _check(self.L.se_amd_reserve(self.h, B), "se_amd_reserve")

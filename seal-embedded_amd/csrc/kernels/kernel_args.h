@@ -30,6 +30,8 @@ struct UniformArgs
     uint32_t B;
     uint32_t prime_lo, prime_hi;
     uint32_t out_primes;
+    uint32_t debug_flags;  // ablation (timing experiments only): 1 = no bulk stores, 2 = no phase 2,
+                           // 4 = no reject bookkeeping
 };
 struct CbdArgs
 {

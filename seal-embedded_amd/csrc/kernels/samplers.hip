@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs 
         // reject test and reduction of one word: sample.c:50-56
         auto word = [&](uint32_t x, uint32_t idx) -> uint32_t {
             uint32_t r = barrett32(x, q, crh);
-            if (x >= bound)
+            if (x >= bound && !(A.debug_flags & 4))
             {
                 if (nrej < A.rej_cap) mylist[nrej] = idx;
                 nrej++;
@@ -101,7 +101,10 @@ __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs 
             {
                 uint32_t w0 = word(st.lo[i], idx + 2 * i);
                 uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
-                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                if (!(A.debug_flags & 1))
+                    *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                else if (w0 == 0x12345678u && w1 == 0x9abcdef0u)
+                    mypoly[0] = w0;  // keeps the values live without storing them
             }
             idx += 34;
         }
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs 
         // ---- phase 2: candidate stream for the rejected coefficients ---------------------
         uint32_t k       = 0;  // rejected coefficients resolved so far
         uint32_t scanpos = 0;  // overflow path: next index to scan for a marker
+        if (A.debug_flags & 2) nrej = 0;
         while (__any(k < nrej))
         {
             KeccakState cs;

@@ -192,7 +192,7 @@ int se_amd_sample_uniform_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const 
     if (rc) return rc;
     const uint32_t np = (uint32_t)ctx->c.hp.nprimes;
     seamd::UniformArgs ua{d_seeds, d_ctr_in, d_ctr_out, d_out, ctx->c.d_rej, ctx->c.rej_cap,
-                          (uint32_t)B, 0, np, np};
+                          (uint32_t)B, 0, np, np, ctx->c.debug_flags};
     SEAMD_HIP(seamd::launch_sample_uniform(ctx->c.dp, ua, as_stream(stream)));
     return SE_SUCCESS;
 }
@@ -255,6 +255,13 @@ int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap)
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;
     ctx->c.rej_cap     = cap;
     ctx->c.scratch_cap = 0;  // force re-allocation with the new stride
+    return SE_SUCCESS;
+}
+
+int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    ctx->c.debug_flags = flags;
     return SE_SUCCESS;
 }
 

@@ -227,7 +227,8 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     stage_end(st);
 
     // a_j for every prime from the shareable seed, written straight into c1 (ckks_sym.c:220)
-    UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np};
+    UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np,
+                   debug_flags};
     stage_begin(1, st);
     SEAMD_HIP(launch_sample_uniform(dp, ua, st));
     stage_end(st);

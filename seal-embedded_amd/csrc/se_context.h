@@ -43,6 +43,7 @@ struct Context
     uint32_t *d_rej    = nullptr;  // [cap][rej_cap]
     size_t scratch_cap = 0;
     uint32_t rej_cap   = 256;
+    uint32_t debug_flags = 0;  // timing ablations of the uniform sampler (tests/tools only)
 
     // profiling
     bool profiling = false;

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdint.h>
 
-#define ITER 2048
+#define ITER 16384
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 #define DEFK(NAME, ASM)                                                                    \
@@ -87,8 +87,10 @@ int main()
 {
     uint32_t* d; hipMalloc(&d, 64 << 20);
 #define R(K) run(#K, K, d);
+    R(k_xor) R(k_bitop3) R(k_bitop3_2) R(k_bfi) R(k_alignbit) R(k_alignbitv) R(k_alignbyte) R(k_perm)
     R(k_and_or) R(k_lshl_or) R(k_lshl_add) R(k_add3) R(k_xad) R(k_add) R(k_sub) R(k_min) R(k_lshl)
     R(k_mul_lo) R(k_mul_hi) R(k_mul_u24) R(k_mad_u24) R(k_mul_hi24) R(k_bcnt) R(k_cndmask) R(k_mov_dpp) R(k_fma32)
+    R(k_lshl64) R(k_fma64) R(k_mul64) R(k_add64) R(k_lshladd64)
     hipFree(d);
     return 0;
 }
