@@ -56,13 +56,13 @@ __device__ __forceinline__ void load_seed(uint32_t (&seed)[16], const uint8_t *s
 constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid residue
 
 template <int LOGN>
-__global__ __launch_bounds__(64) void k_sample_uniform(DevParams P, UniformArgs A)
+__global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArgs A)
 {
     constexpr int N          = 1 << LOGN;
     constexpr int FULL_STEPS = (N * 4) / 136;            // permutations that yield 34 words
     constexpr int TAIL_WORDS = N - FULL_STEPS * 34;      // words taken from one more permutation
 
-    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= A.B) return;
 
     uint32_t seed[16];
@@ -222,9 +222,9 @@ __device__ __forceinline__ uint32_t mod3_u8(uint32_t r)
     return r - 3u * ((r * 171u) >> 9);
 }
 
-__global__ __launch_bounds__(64) void k_sample_ternary(TernaryArgs A)
+__global__ __launch_bounds__(1024) void k_sample_ternary(TernaryArgs A)
 {
-    const size_t b    = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t b    = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = b < A.B;
     const size_t bs   = active ? b : (size_t)A.B - 1;
     const uint32_t n  = A.n;
@@ -325,19 +325,46 @@ __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// Lane-per-ciphertext kernels run ONE long sequential chain per lane, so the kernel lasts as long
+// as its slowest SIMD: the waves must be spread evenly over the chip.  Left to the dispatcher,
+// 1-wave workgroups launched behind another kernel were observed to pile 2 waves on some SIMDs
+// and none on others (k_sample_uniform 7.0 ms alone -> 11.4 ms in the pipeline).  We therefore
+// launch workgroups of w waves (w = 4, 8, 12, 16: one..four per SIMD) and reserve > 80 KiB of
+// dynamic LDS per workgroup, which admits exactly one workgroup per CU: every CU gets the same
+// number of waves and the hardware deals a workgroup's waves round-robin over its 4 SIMDs.
+static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &lds_bytes)
+{
+    const size_t waves = (B + 63) / 64;
+    size_t per_cu      = (waves + 255) / 256;   // waves per CU if spread over 256 CUs
+    size_t w           = ((per_cu + 3) / 4) * 4;
+    if (w < 4) w = 4;
+    if (w > 16) w = 16;
+    threads   = (unsigned)(w * 64);
+    grid      = (unsigned)((B + threads - 1) / threads);
+    lds_bytes = 84 * 1024;
+}
+
 hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A, hipStream_t st)
 {
     if (A.B == 0) return hipSuccess;
-    dim3 grid((A.B + 63) / 64), block(64);
+    unsigned threads, grid_x;
+    size_t lds;
+    chain_geometry(A.B, threads, grid_x, lds);
+    dim3 grid(grid_x), block(threads);
+#define SEAMD_LAUNCH_UNIFORM(L)                                                                  \
+    (void)hipFuncSetAttribute((const void *)k_sample_uniform<L>,                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL(k_sample_uniform<L>, grid, block, lds, st, P, A)
     switch (P.logn)
     {
-        case 10: hipLaunchKernelGGL(k_sample_uniform<10>, grid, block, 0, st, P, A); break;
-        case 11: hipLaunchKernelGGL(k_sample_uniform<11>, grid, block, 0, st, P, A); break;
-        case 12: hipLaunchKernelGGL(k_sample_uniform<12>, grid, block, 0, st, P, A); break;
-        case 13: hipLaunchKernelGGL(k_sample_uniform<13>, grid, block, 0, st, P, A); break;
-        case 14: hipLaunchKernelGGL(k_sample_uniform<14>, grid, block, 0, st, P, A); break;
+        case 10: SEAMD_LAUNCH_UNIFORM(10); break;
+        case 11: SEAMD_LAUNCH_UNIFORM(11); break;
+        case 12: SEAMD_LAUNCH_UNIFORM(12); break;
+        case 13: SEAMD_LAUNCH_UNIFORM(13); break;
+        case 14: SEAMD_LAUNCH_UNIFORM(14); break;
         default: return hipErrorInvalidValue;
     }
+#undef SEAMD_LAUNCH_UNIFORM
     return hipGetLastError();
 }
 
@@ -352,7 +379,12 @@ hipError_t launch_sample_cbd(const CbdArgs &A, hipStream_t st)
 hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
 {
     if (A.B == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sample_ternary, dim3((A.B + 63) / 64), dim3(64), 0, st, A);
+    unsigned threads, grid_x;
+    size_t lds;
+    chain_geometry(A.B, threads, grid_x, lds);
+    (void)hipFuncSetAttribute((const void *)k_sample_ternary, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(k_sample_ternary, dim3(grid_x), dim3(threads), lds, st, A);
     return hipGetLastError();
 }
 
