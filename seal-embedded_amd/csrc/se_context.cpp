@@ -34,6 +34,9 @@ Context::~Context()
         (void)hipEventDestroy(ev.start);
         (void)hipEventDestroy(ev.stop);
     }
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1,
                     d_err,     d_ucodes, d_ctr,    d_rej};
     for (void *p : ptrs)
@@ -81,6 +84,9 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipMemcpy(d_ifft_w, w.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
     SEAMD_HIP(hipMemcpy(d_ntt_rw, rw_all.data(), rw_all.size() * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
+    SEAMD_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    SEAMD_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    SEAMD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     dt.inv_map = d_inv_map;
     dt.ifft_w  = d_ifft_w;
     dt.ntt_rw  = d_ntt_rw;
@@ -220,11 +226,20 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
 
-    // e: n/16 CBD blocks per ciphertext from the secret seed, counters 0.. (ckks_sym.c:196)
+    // e: n/16 CBD blocks per ciphertext from the secret seed, counters 0.. (ckks_sym.c:196).
+    // Independent of `a`, so it runs on the auxiliary stream beside the uniform sampler (whose
+    // one-wave-per-SIMD chains leave issue slots free) and is joined before the fused kernel.
+    hipStream_t cbd_stream = overlap ? aux_stream : st;
+    if (overlap)
+    {
+        SEAMD_HIP(hipEventRecord(ev_fork, st));
+        SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+    }
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
-    stage_begin(0, st);
-    SEAMD_HIP(launch_sample_cbd(ca, st));
-    stage_end(st);
+    stage_begin(0, cbd_stream);
+    SEAMD_HIP(launch_sample_cbd(ca, cbd_stream));
+    stage_end(cbd_stream);
+    if (overlap) SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
 
     // a_j for every prime from the shareable seed, written straight into c1 (ckks_sym.c:220)
     UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np,
@@ -232,6 +247,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     stage_begin(1, st);
     SEAMD_HIP(launch_sample_uniform(dp, ua, st));
     stage_end(st);
+    if (overlap) SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
 
     EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
     stage_begin(3, st);

@@ -45,6 +45,12 @@ struct Context
     uint32_t rej_cap   = 256;
     uint32_t debug_flags = 0;  // timing ablations of the uniform sampler (tests/tools only)
 
+    // second stream: the CBD error sampler runs beside the uniform sampler (different seeds, no
+    // data dependency); joined before the fused encode+encrypt kernel.
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;
+
     // profiling
     bool profiling = false;
     std::vector<StageEvent> events;
