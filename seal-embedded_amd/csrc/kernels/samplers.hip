@@ -329,15 +329,15 @@ __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const 
 // as its slowest SIMD: the waves must be spread evenly over the chip.  Left to the dispatcher,
 // 1-wave workgroups launched behind another kernel were observed to pile 2 waves on some SIMDs
 // and none on others (k_sample_uniform 7.0 ms alone -> 11.4 ms in the pipeline).  We therefore
-// launch workgroups of w waves (w = 4, 8, 12, 16: one..four per SIMD) and reserve > 80 KiB of
-// dynamic LDS per workgroup, which admits exactly one workgroup per CU: every CU gets the same
-// number of waves and the hardware deals a workgroup's waves round-robin over its 4 SIMDs.
+// launch workgroups of w waves (w = 1, 2, 3, 4, 8, 12, 16) and reserve > 80 KiB of dynamic LDS per
+// workgroup, which admits exactly one workgroup per CU: every CU gets the same number of waves
+// and the hardware deals a workgroup's waves round-robin over its 4 SIMDs.
 static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &lds_bytes)
 {
     const size_t waves = (B + 63) / 64;
-    size_t per_cu      = (waves + 255) / 256;   // waves per CU if spread over 256 CUs
-    size_t w           = ((per_cu + 3) / 4) * 4;
-    if (w < 4) w = 4;
+    size_t w           = (waves + 255) / 256;   // waves per CU if spread over 256 CUs
+    if (w < 1) w = 1;
+    if (w > 4) w = ((w + 3) / 4) * 4;           // beyond one per SIMD: whole multiples of 4
     if (w > 16) w = 16;
     threads   = (unsigned)(w * 64);
     grid      = (unsigned)((B + threads - 1) / threads);
