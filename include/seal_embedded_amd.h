@@ -206,8 +206,10 @@ enum
     SE_AMD_STAGE_CBD = 0,
     SE_AMD_STAGE_UNIFORM = 1,
     SE_AMD_STAGE_TERNARY = 2,
-    SE_AMD_STAGE_ENCODE_ENCRYPT = 3,
-    SE_AMD_STAGE_COUNT = 4
+    SE_AMD_STAGE_ENCODE_ENCRYPT = 3, /* fused kernel (asymmetric, encode-only, unsplit symmetric) */
+    SE_AMD_STAGE_ENCODE_RNS = 4,     /* split symmetric path: encode -> RNS residues */
+    SE_AMD_STAGE_NTT_FUSE = 5,       /* split symmetric path: per-prime NTT + ciphertext arithmetic */
+    SE_AMD_STAGE_COUNT = 6
 };
 int se_amd_set_profiling(se_amd_ctx *ctx, int enabled);
 int se_amd_stage_ms(se_amd_ctx *ctx, float *ms /*[SE_AMD_STAGE_COUNT]*/,
@@ -220,6 +222,9 @@ int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
 int se_amd_reserve(se_amd_ctx *ctx, size_t B);
 /* timing ablations of the uniform sampler (tools/ablate.py); outputs are WRONG when non-zero. */
 int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags);
+/* pipeline shape of the symmetric path (A/B experiments): overlap = use the auxiliary stream,
+ * split = per-prime software pipeline (default 1, 1). */
+int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split);
 const char *se_amd_last_error(void);
 const char *se_amd_version(void);
 

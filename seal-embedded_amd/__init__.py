@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libseal_embedded_amd.so")
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include", "seal_embedded_amd.h")
 
-STAGES = ("cbd", "uniform", "ternary", "encode_encrypt")
+STAGES = ("cbd", "uniform", "ternary", "encode_encrypt", "encode_rns", "ntt_fuse")
 
 SE_SUCCESS = 0
 
@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
     "se_amd_pack_ternary_host", "se_amd_set_profiling", "se_amd_stage_ms",
-    "se_amd_set_reject_list_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -97,6 +97,7 @@ def lib():
     L.se_amd_set_reject_list_capacity.argtypes = [vp, u32]
     L.se_amd_reserve.argtypes = [vp, sz]
     L.se_amd_set_debug_flags.argtypes = [vp, u32]
+    L.se_amd_set_pipeline.argtypes = [vp, i32, i32]
     _lib = L
     return L
 
@@ -276,6 +277,9 @@ class Context:
         cnt = (C.c_uint64 * len(STAGES))()
         _check(self.L.se_amd_stage_ms(self.h, ms, cnt, 1 if reset else 0), "se_amd_stage_ms")
         return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(STAGES)}
+
+    def set_pipeline(self, overlap=True, split=True):
+        _check(self.L.se_amd_set_pipeline(self.h, int(overlap), int(split)), "se_amd_set_pipeline")
 
     def set_debug_flags(self, flags):
         _check(self.L.se_amd_set_debug_flags(self.h, flags), "se_amd_set_debug_flags")

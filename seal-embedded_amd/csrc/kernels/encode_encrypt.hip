@@ -61,28 +61,27 @@ __device__ __forceinline__ void load16_pairs(uint32_t (&w)[16], uint32_t (&wp)[1
     }
 }
 
-template <int LOGN, int MODE>
-__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(DevParams P, DevTables T,
-                                                                          EncArgs A)
+// ------------------------------------------------------------------------------------------
+// Encode front end shared by the fused and the split kernels: values -> LDS -> gather through the
+// inverse index map -> inverse FFT -> round to int64 (+ overflow status).  On return thread t owns
+// the plaintext coefficients k = t + (n/16)*e, e = 0..15, and the workgroup is synchronised.
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTables &T,
+                                                 const float *values, uint8_t *status, size_t b,
+                                                 unsigned char *smem, int64_t (&m)[16])
 {
-    using G            = XformGeom<LOGN>;
-    constexpr int N    = G::N;
-    constexpr int TH   = G::THREADS;
-    constexpr int CTOP = LOGN - 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *plane   = reinterpret_cast<double *>(smem);
-    uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
-    float *sv       = reinterpret_cast<float *>(smem);
+    using G          = XformGeom<LOGN>;
+    constexpr int N  = G::N;
+    constexpr int TH = G::THREADS;
+    double *plane    = reinterpret_cast<double *>(smem);
+    float *sv        = reinterpret_cast<float *>(smem);
+    const int t      = threadIdx.x;
 
-    const int t    = threadIdx.x;
-    const size_t b = blockIdx.x;
-    const int np   = P.nprimes;
-
-    // ---- 1. values -> LDS (coalesced), then gather through the inverse index map -----------
     // ckks_common.c:139-153 scatters values[i] to both conjugate slots; the map is a bijection
     // onto [0,n), so slot k is filled from values[inv_map[k] mod n/2].
     {
-        const float4 *src = reinterpret_cast<const float4 *>(A.values + b * (N / 2));
+        const float4 *src = reinterpret_cast<const float4 *>(values + b * (N / 2));
         float4 *dst       = reinterpret_cast<float4 *>(sv);
 #pragma unroll
         for (int i = t; i < N / 8; i += TH) dst[i] = src[i];
@@ -103,11 +102,10 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(Dev
     }
     __syncthreads();
 
-    // ---- 2. inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183) ----------------------
+    // inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183)
     ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
 
-    // ---- 3. round to int64, overflow check, add the error polynomial -------------------------
-    int64_t m[16];
+    // round to int64, overflow check (ckks_common.c:183-206)
     int ok = 1;
 #pragma unroll
     for (int e = 0; e < 16; e++)
@@ -117,7 +115,25 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(Dev
         m[e] = (int64_t)c;
     }
     ok = __syncthreads_and(ok);
-    if (A.status && t == 0) A.status[b] = (uint8_t)ok;
+    if (status && t == 0) status[b] = (uint8_t)ok;
+}
+
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(DevParams P, DevTables T,
+                                                                          EncArgs A)
+{
+    using G            = XformGeom<LOGN>;
+    constexpr int N    = G::N;
+    constexpr int CTOP = LOGN - 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
+
+    const int t    = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int np   = P.nprimes;
+
+    int64_t m[16];
+    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m);
 
     // thread t now owns points k = t + (n/16)*e
     if constexpr (MODE == kModeSym)
@@ -180,8 +196,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(Dev
                 store16(A.c1 + off, out);
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
-#pragma unroll
-            for (int e = 0; e < 16; e++) x[e] = reduce_signed(m[e], q, crh, crl);
+            reduce_signed16(m, x, q, crh, crl);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -201,8 +216,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(Dev
         else
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
-#pragma unroll
-            for (int e = 0; e < 16; e++) x[e] = reduce_signed(m[e], q, crh, crl);
+            reduce_signed16(m, x, q, crh, crl);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -226,6 +240,95 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_encrypt(Dev
                 store16(A.c0 + off, x);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split form of the symmetric path, used so that everything that does not need `a` overlaps with
+// the (long, one-wave-per-SIMD) uniform sampler:
+//   k_encode_rns : encode -> + e -> per prime signed reduction, residues stored (natural order)
+//                  into the c0 slab itself -- no extra scratch.
+//   k_ntt_fuse   : prime j of every ciphertext: load residues from c0_j, forward NTT, then
+//                  c0_j = NTT(m+e) - s_hat . a_j  with a_j read from c1_j (ckks_sym.c:273-300).
+// ------------------------------------------------------------------------------------------
+template <int LOGN, bool ADD_ERR>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevParams P, DevTables T,
+                                                                      EncArgs A)
+{
+    using G            = XformGeom<LOGN>;
+    constexpr int N    = G::N;
+    constexpr int CTOP = LOGN - 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t    = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int np   = P.nprimes;
+
+    int64_t m[16];
+    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m);
+    if constexpr (ADD_ERR)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) m[e] += A.err[b * N + (e << CTOP) + t];
+    }
+    if (A.pte)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) A.pte[b * N + (e << CTOP) + t] = m[e];
+    }
+    for (int j = 0; j < np; j++)
+    {
+        uint32_t x[16];
+        reduce_signed16(m, x, P.q[j], P.cr_hi[j], P.cr_lo[j]);
+        uint32_t *dst = A.c0 + (b * np + j) * N;
+#pragma unroll
+        for (int e = 0; e < 16; e++) dst[(e << CTOP) + t] = x[e];
+    }
+}
+
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_ntt_fuse(DevParams P, DevTables T, EncArgs A,
+                                                                    int j)
+{
+    using G            = XformGeom<LOGN>;
+    constexpr int N    = G::N;
+    constexpr int CTOP = LOGN - 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds32  = reinterpret_cast<uint32_t *>(smem);
+    const int t      = threadIdx.x;
+    const size_t b   = blockIdx.x;
+    const int np     = P.nprimes;
+    const uint32_t q = P.q[j], two_q = q << 1;
+    uint32_t *poly   = A.c0 + (b * np + j) * N;
+    const size_t off = (b * np + j) * N + 16 * t;
+
+    uint32_t x[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = poly[(e << CTOP) + t];
+    // issue the epilogue operands now; they land while the NTT runs
+    uint32_t a[16], w[16], wp[16];
+    if constexpr (MODE == kModeSym)
+    {
+        load16(a, A.c1 + off);
+        load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+    }
+    ntt_tiles<LOGN>(x, T.ntt_rw + (size_t)2 * N * j, q, lds32, t);
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+    if (A.ntt_pte) store16(A.ntt_pte + off, x);
+    if constexpr (MODE == kModeSym)
+    {
+        uint32_t out[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
+            out[e]      = csub(x[e] + q - pr, q);
+        }
+        store16(poly + 16 * t, out);
+    }
+    else
+    {
+        store16(poly + 16 * t, x);
     }
 }
 
@@ -320,6 +423,80 @@ hipError_t launch_encode_encrypt(const DevParams &P, const DevTables &T, const E
         case 12: return launch_enc<12>(P, T, A, mode, B, st);
         case 13: return launch_enc<13>(P, T, A, mode, B, st);
         case 14: return launch_enc<14>(P, T, A, mode, B, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_enc_rns(const DevParams &P, const DevTables &T, const EncArgs &A, bool add_err,
+                                 size_t B, hipStream_t st)
+{
+    using G      = XformGeom<LOGN>;
+    size_t shmem = (size_t)G::SLOTS * sizeof(double);
+    dim3 grid((unsigned)B), block(G::THREADS);
+    if (add_err)
+    {
+        (void)hipFuncSetAttribute((const void *)k_encode_rns<LOGN, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL((k_encode_rns<LOGN, true>), grid, block, shmem, st, P, T, A);
+    }
+    else
+    {
+        (void)hipFuncSetAttribute((const void *)k_encode_rns<LOGN, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL((k_encode_rns<LOGN, false>), grid, block, shmem, st, P, T, A);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_rns(const DevParams &P, const DevTables &T, const EncArgs &A, bool add_err,
+                             size_t B, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    switch (P.logn)
+    {
+        case 10: return launch_enc_rns<10>(P, T, A, add_err, B, st);
+        case 11: return launch_enc_rns<11>(P, T, A, add_err, B, st);
+        case 12: return launch_enc_rns<12>(P, T, A, add_err, B, st);
+        case 13: return launch_enc_rns<13>(P, T, A, add_err, B, st);
+        case 14: return launch_enc_rns<14>(P, T, A, add_err, B, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_nf(const DevParams &P, const DevTables &T, const EncArgs &A, int mode, int j,
+                            size_t B, hipStream_t st)
+{
+    using G      = XformGeom<LOGN>;
+    size_t shmem = (size_t)G::SLOTS * sizeof(uint32_t);
+    dim3 grid((unsigned)B), block(G::THREADS);
+    if (mode == kModeSym)
+    {
+        (void)hipFuncSetAttribute((const void *)k_ntt_fuse<LOGN, kModeSym>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL((k_ntt_fuse<LOGN, kModeSym>), grid, block, shmem, st, P, T, A, j);
+    }
+    else
+    {
+        (void)hipFuncSetAttribute((const void *)k_ntt_fuse<LOGN, kModeEncodeOnly>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL((k_ntt_fuse<LOGN, kModeEncodeOnly>), grid, block, shmem, st, P, T, A, j);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_fuse(const DevParams &P, const DevTables &T, const EncArgs &A, int mode, int j,
+                           size_t B, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    switch (P.logn)
+    {
+        case 10: return launch_nf<10>(P, T, A, mode, j, B, st);
+        case 11: return launch_nf<11>(P, T, A, mode, j, B, st);
+        case 12: return launch_nf<12>(P, T, A, mode, j, B, st);
+        case 13: return launch_nf<13>(P, T, A, mode, j, B, st);
+        case 14: return launch_nf<14>(P, T, A, mode, j, B, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -52,6 +52,10 @@ struct TernaryArgs
 
 hipError_t launch_encode_encrypt(const DevParams &, const DevTables &, const EncArgs &, int mode,
                                  size_t B, hipStream_t);
+hipError_t launch_encode_rns(const DevParams &, const DevTables &, const EncArgs &, bool add_err,
+                             size_t B, hipStream_t);
+hipError_t launch_ntt_fuse(const DevParams &, const DevTables &, const EncArgs &, int mode, int j,
+                           size_t B, hipStream_t);
 hipError_t launch_ntt_polys(const DevParams &, const DevTables &, int j, uint32_t *polys,
                             uint32_t *pairs, size_t count, hipStream_t);
 hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, size_t count,

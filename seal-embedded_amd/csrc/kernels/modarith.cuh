@@ -50,14 +50,49 @@ __device__ __forceinline__ uint32_t reduce_signed(int64_t x, uint32_t q, uint32_
     return x < 0 ? q - r : r;
 }
 
-// Harvey butterfly, inputs/outputs in [0,4q): (X, Y) -> (X + Y*w, X - Y*w)  (ntt.c:156-162)
+// Harvey butterfly, inputs/outputs in [0,4q): (X, Y) -> (X + Y*w, X - Y*w)  (ntt.c:156-162).
+// 8 VALU ops: mul_hi, mul_lo, mad_u64_u32 (y*w - h*q as h*(2^32-q) + y*w mod 2^32), sub, min,
+// add, add, sub.
 __device__ __forceinline__ void ct_butterfly(uint32_t &x, uint32_t &y, uint32_t w, uint32_t wp,
-                                             uint32_t q, uint32_t two_q)
+                                             uint32_t neg_q, uint32_t two_q)
 {
     uint32_t u = min(x, x - two_q);
-    uint32_t t = mul_shoup_lazy(y, w, wp, q);
+    uint32_t h = __umulhi(y, wp);
+    uint32_t t = (uint32_t)((uint64_t)h * (uint64_t)neg_q + (uint64_t)(y * w));  // [0,2q)
     x          = u + t;
-    y          = u - t + two_q;
+    y          = (u + two_q) - t;
+}
+
+// 16 signed plaintext coefficients -> residues.  When every magnitude in the WAVE fits 32 bits
+// (the normal case: |m| ~ scale * |value|) the 64-bit Barrett collapses to the one-multiply
+// 32-bit form; otherwise all lanes take the general path.  Both give x mod q exactly.
+__device__ __forceinline__ void reduce_signed16(const int64_t (&m)[16], uint32_t (&x)[16], uint32_t q,
+                                                uint32_t cr_hi, uint32_t cr_lo)
+{
+    uint32_t any_hi = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        uint64_t mag = m[e] < 0 ? (uint64_t)0 - (uint64_t)m[e] : (uint64_t)m[e];
+        any_hi |= (uint32_t)(mag >> 32);
+    }
+    if (__all(any_hi == 0))
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            uint32_t lo  = (uint32_t)m[e];
+            bool neg     = m[e] < 0;
+            uint32_t mag = neg ? 0u - lo : lo;
+            uint32_t r   = barrett32(mag, q, cr_hi);
+            x[e]         = neg ? q - r : r;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) x[e] = reduce_signed(m[e], q, cr_hi, cr_lo);
+    }
 }
 
 // [0,4q) -> [0,q)

@@ -86,7 +86,9 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
                                           const double *__restrict__ W, int t)
 {
     constexpr int N = 1 << LOGN;
-    const int thi   = t >> C;
+    // top window: t < n/16 = 2^C, so t >> C == 0 and the root indices are compile-time constants
+    // (uniform addresses -> scalar loads, no VGPRs)
+    const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
     static_for<B_LO, B_HI>([&](auto bc) {
         constexpr int b      = decltype(bc)::value;
         constexpr int h      = N >> (C + b + 1);
@@ -145,10 +147,10 @@ __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
 // ------------------------------------------------------------------------------------------
 template <int LOGN, int C, int B_LO, int B_HI>
 __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
-                                         uint32_t q, uint32_t two_q, int t)
+                                         uint32_t neg_q, uint32_t two_q, int t)
 {
     constexpr int N = 1 << LOGN;
-    const int thi   = t >> C;
+    const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
     static_for<0, B_HI - B_LO>([&](auto sc) {
         constexpr int b      = B_HI - 1 - decltype(sc)::value;  // descending
         constexpr int h      = N >> (C + b + 1);
@@ -160,7 +162,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
-                ct_butterfly(x[e0], x[e1], rw.x, rw.y, q, two_q);
+                ct_butterfly(x[e0], x[e1], rw.x, rw.y, neg_q, two_q);
             });
         });
     });
@@ -174,23 +176,24 @@ __device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__r
 {
     using G              = XformGeom<LOGN>;
     const uint32_t two_q = q << 1;
+    const uint32_t neg_q = 0u - q;
     constexpr int C0     = LOGN - 4;
-    ntt_pass<LOGN, C0, 0, 4>(x, RW, q, two_q, t);
+    ntt_pass<LOGN, C0, 0, 4>(x, RW, neg_q, two_q, t);
     constexpr int C1 = G::ntt_c(1);  // LOGN - 8
     redeal<C0, C1>(x, lds, t);
-    ntt_pass<LOGN, C1, 0, 4>(x, RW, q, two_q, t);
+    ntt_pass<LOGN, C1, 0, 4>(x, RW, neg_q, two_q, t);
     if constexpr (LOGN <= 12)
     {
         redeal<C1, 0>(x, lds, t);
-        ntt_pass<LOGN, 0, 0, C1>(x, RW, q, two_q, t);  // remaining bits C1-1 .. 0
+        ntt_pass<LOGN, 0, 0, C1>(x, RW, neg_q, two_q, t);  // remaining bits C1-1 .. 0
     }
     else
     {
         constexpr int C2 = G::ntt_c(2);  // LOGN - 12 (1 or 2)
         redeal<C1, C2>(x, lds, t);
-        ntt_pass<LOGN, C2, 0, 4>(x, RW, q, two_q, t);
+        ntt_pass<LOGN, C2, 0, 4>(x, RW, neg_q, two_q, t);
         redeal<C2, 0>(x, lds, t);
-        ntt_pass<LOGN, 0, 0, C2>(x, RW, q, two_q, t);
+        ntt_pass<LOGN, 0, 0, C2>(x, RW, neg_q, two_q, t);
     }
 }
 

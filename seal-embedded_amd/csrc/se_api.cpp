@@ -265,6 +265,14 @@ int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags)
     return SE_SUCCESS;
 }
 
+int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    ctx->c.overlap = overlap != 0;
+    ctx->c.split   = split != 0;
+    return SE_SUCCESS;
+}
+
 int se_amd_reserve(se_amd_ctx *ctx, size_t B)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;

@@ -37,6 +37,8 @@ Context::~Context()
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    for (auto &e : ev_prime)
+        if (e) (void)hipEventDestroy(e);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1,
                     d_err,     d_ucodes, d_ctr,    d_rej};
     for (void *p : ptrs)
@@ -87,6 +89,8 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    for (size_t j = 0; j < nprimes; j++)
+        SEAMD_HIP(hipEventCreateWithFlags(&ev_prime[j], hipEventDisableTiming));
     dt.inv_map = d_inv_map;
     dt.ifft_w  = d_ifft_w;
     dt.ntt_rw  = d_ntt_rw;
@@ -226,32 +230,69 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
 
-    // e: n/16 CBD blocks per ciphertext from the secret seed, counters 0.. (ckks_sym.c:196).
-    // Independent of `a`, so it runs on the auxiliary stream beside the uniform sampler (whose
-    // one-wave-per-SIMD chains leave issue slots free) and is joined before the fused kernel.
-    hipStream_t cbd_stream = overlap ? aux_stream : st;
-    if (overlap)
-    {
-        SEAMD_HIP(hipEventRecord(ev_fork, st));
-        SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
-    }
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
-    stage_begin(0, cbd_stream);
-    SEAMD_HIP(launch_sample_cbd(ca, cbd_stream));
-    stage_end(cbd_stream);
-    if (overlap) SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
-
-    // a_j for every prime from the shareable seed, written straight into c1 (ckks_sym.c:220)
-    UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np,
-                   debug_flags};
-    stage_begin(1, st);
-    SEAMD_HIP(launch_sample_uniform(dp, ua, st));
-    stage_end(st);
-    if (overlap) SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
-
     EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
-    stage_begin(3, st);
-    SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
+
+    if (!(split && overlap))
+    {
+        // Simple chain: [cbd on the aux stream || uniform] -> fused encode+encrypt.
+        hipStream_t cbd_stream = overlap ? aux_stream : st;
+        if (overlap)
+        {
+            SEAMD_HIP(hipEventRecord(ev_fork, st));
+            SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+        }
+        stage_begin(0, cbd_stream);
+        SEAMD_HIP(launch_sample_cbd(ca, cbd_stream));
+        stage_end(cbd_stream);
+        if (overlap) SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
+        UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np,
+                       debug_flags};
+        stage_begin(1, st);
+        SEAMD_HIP(launch_sample_uniform(dp, ua, st));
+        stage_end(st);
+        if (overlap) SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        stage_begin(3, st);
+        SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
+        stage_end(st);
+        return 0;
+    }
+
+    // Software pipeline over the primes.  The uniform sampler is one long sequential chain per
+    // ciphertext that keeps ONE wave per SIMD busy; everything that does not need a_j runs beside
+    // it on the auxiliary stream:
+    //   S : U_0 ──► U_1 ──► ... ──► U_{np-1} ─────────────► N_{np-1}
+    //   A : cbd ► encode_rns ► (wait U_0) N_0 ► (wait U_1) N_1 ► ... ┘(join)
+    // U_j = k_sample_uniform for prime j (counter carried in d_ctr), N_j = k_ntt_fuse for prime j.
+    SEAMD_HIP(hipEventRecord(ev_fork, st));
+    SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+    stage_begin(0, aux_stream);
+    SEAMD_HIP(launch_sample_cbd(ca, aux_stream));  // e, counters 0.. (ckks_sym.c:196)
+    stage_end(aux_stream);
+    stage_begin(4, aux_stream);
+    SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, aux_stream));
+    stage_end(aux_stream);
+    for (uint32_t j = 0; j < np; j++)
+    {
+        // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
+        UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
+                       j,             j + 1,               np,    debug_flags};
+        stage_begin(1, st);
+        SEAMD_HIP(launch_sample_uniform(dp, ua, st));
+        stage_end(st);
+        if (j + 1 < np)
+        {
+            SEAMD_HIP(hipEventRecord(ev_prime[j], st));
+            SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_prime[j], 0));
+            stage_begin(5, aux_stream);
+            SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, B, aux_stream));
+            stage_end(aux_stream);
+        }
+    }
+    SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
+    SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    stage_begin(5, st);
+    SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)np - 1, B, st));
     stage_end(st);
     return 0;
 }

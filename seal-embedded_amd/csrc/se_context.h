@@ -11,7 +11,7 @@
 
 namespace seamd {
 
-constexpr int kStageCount = 4;
+constexpr int kStageCount = 6;  // cbd, uniform, ternary, encode_encrypt (fused), encode_rns, ntt_fuse
 
 struct StageEvent
 {
@@ -49,13 +49,15 @@ struct Context
     // data dependency); joined before the fused encode+encrypt kernel.
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool overlap = true;
+    hipEvent_t ev_prime[kMaxPrimes] = {};
+    bool overlap = true;   // run independent kernels on the auxiliary stream
+    bool split   = true;   // symmetric path as encode_rns + per-prime (uniform_j || ntt_fuse_{j-1})
 
     // profiling
     bool profiling = false;
     std::vector<StageEvent> events;
-    float stage_ms[kStageCount]          = {0, 0, 0, 0};
-    uint64_t stage_launches[kStageCount] = {0, 0, 0, 0};
+    float stage_ms[kStageCount]          = {};
+    uint64_t stage_launches[kStageCount] = {};
 
     ~Context();
     int init(size_t n, size_t nprimes, int device);

@@ -25,11 +25,13 @@ def timed(f, reps=3):
 print("uniform alone (bench seeds, c1 buffer): %.3f ms" % timed(lambda: ctx.sample_uniform(ss, c1)))
 print("cbd alone: %.3f ms" % timed(lambda: ctx.sample_cbd(sd, err, n // 16)))
 print("cbd+uniform back to back: %.3f ms" % timed(lambda: (ctx.sample_cbd(sd, err, n // 16), ctx.sample_uniform(ss, c1))))
-print("full encrypt_sym: %.3f ms" % timed(lambda: ctx.encrypt_sym(vals, ss, sd, c0, c1)))
-ctx.set_profiling(True); ctx.stage_ms(True)
-for _ in range(3): ctx.encrypt_sym(vals, ss, sd, c0, c1)
-torch.cuda.synchronize(); print("stages:", {k: v[0] / max(v[1], 1) for k, v in ctx.stage_ms(True).items()})
-ctx.set_profiling(False)
+for ov, sp in ((0, 0), (1, 0), (1, 1)):
+    ctx.set_pipeline(ov, sp)
+    print("full encrypt_sym overlap=%d split=%d: %.3f ms" % (ov, sp, timed(lambda: ctx.encrypt_sym(vals, ss, sd, c0, c1), reps=5)))
+    ctx.set_profiling(True); ctx.stage_ms(True)
+    for _ in range(3): ctx.encrypt_sym(vals, ss, sd, c0, c1)
+    torch.cuda.synchronize(); print("   stages (ms per step):", {k: round(v[0] / 3, 3) for k, v in ctx.stage_ms(True).items() if v[1]})
+    ctx.set_profiling(False)
 print("uniform alone again: %.3f ms" % timed(lambda: ctx.sample_uniform(ss, c1)))
 # sustained: 20 back-to-back uniform launches
 print("uniform x20 sustained: %.3f ms each" % timed(lambda: ctx.sample_uniform(ss, c1), reps=20))

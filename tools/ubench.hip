@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_butterfly(uint32_t* out, uint32_t q)
     for (int c = 0; c < 8; c++) { x[c] = threadIdx.x + c; y[c] = blockIdx.x + 7 * c; }
     for (int i = 0; i < ITER; i++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) seamd::ct_butterfly(x[c], y[c], w, wp, q, q << 1);
+        for (int c = 0; c < 8; c++) seamd::ct_butterfly(x[c], y[c], w, wp, 0u - q, q << 1);
     uint32_t acc = 0;
     for (int c = 0; c < 8; c++) acc ^= x[c] ^ y[c];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
