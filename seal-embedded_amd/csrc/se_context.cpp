@@ -67,7 +67,8 @@ int Context::init(size_t n, size_t nprimes, int dev)
     device = dev;
     SEAMD_HIP(hipSetDevice(device));
     dp = to_dev_params(hp);
-    rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);  // >= 3x the expected rejections per polynomial
+    rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
+    split   = n >= 8192;  // >= 3x the expected rejections per polynomial
 
     std::vector<uint16_t> inv;
     host_index_map(hp, index_map, inv);
@@ -233,7 +234,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
     EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
 
-    if (!(split && overlap))
+    if (!split)
     {
         // Simple chain: [cbd on the aux stream || uniform] -> fused encode+encrypt.
         hipStream_t cbd_stream = overlap ? aux_stream : st;
@@ -264,14 +265,18 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     //   S : U_0 ──► U_1 ──► ... ──► U_{np-1} ─────────────► N_{np-1}
     //   A : cbd ► encode_rns ► (wait U_0) N_0 ► (wait U_1) N_1 ► ... ┘(join)
     // U_j = k_sample_uniform for prime j (counter carried in d_ctr), N_j = k_ntt_fuse for prime j.
-    SEAMD_HIP(hipEventRecord(ev_fork, st));
-    SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
-    stage_begin(0, aux_stream);
-    SEAMD_HIP(launch_sample_cbd(ca, aux_stream));  // e, counters 0.. (ckks_sym.c:196)
-    stage_end(aux_stream);
-    stage_begin(4, aux_stream);
-    SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, aux_stream));
-    stage_end(aux_stream);
+    hipStream_t ax = overlap ? aux_stream : st;
+    if (overlap)
+    {
+        SEAMD_HIP(hipEventRecord(ev_fork, st));
+        SEAMD_HIP(hipStreamWaitEvent(ax, ev_fork, 0));
+    }
+    stage_begin(0, ax);
+    SEAMD_HIP(launch_sample_cbd(ca, ax));  // e, counters 0.. (ckks_sym.c:196)
+    stage_end(ax);
+    stage_begin(4, ax);
+    SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, ax));
+    stage_end(ax);
     for (uint32_t j = 0; j < np; j++)
     {
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
@@ -282,15 +287,21 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
         stage_end(st);
         if (j + 1 < np)
         {
-            SEAMD_HIP(hipEventRecord(ev_prime[j], st));
-            SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_prime[j], 0));
-            stage_begin(5, aux_stream);
-            SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, B, aux_stream));
-            stage_end(aux_stream);
+            if (overlap)
+            {
+                SEAMD_HIP(hipEventRecord(ev_prime[j], st));
+                SEAMD_HIP(hipStreamWaitEvent(ax, ev_prime[j], 0));
+            }
+            stage_begin(5, ax);
+            SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, B, ax));
+            stage_end(ax);
         }
     }
-    SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
-    SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    if (overlap)
+    {
+        SEAMD_HIP(hipEventRecord(ev_join, ax));
+        SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    }
     stage_begin(5, st);
     SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)np - 1, B, st));
     stage_end(st);

@@ -51,7 +51,9 @@ struct Context
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_prime[kMaxPrimes] = {};
     bool overlap = true;   // run independent kernels on the auxiliary stream
-    bool split   = true;   // symmetric path as encode_rns + per-prime (uniform_j || ntt_fuse_{j-1})
+    bool split   = false;  // symmetric path as encode_rns + per-prime (uniform_j || ntt_fuse_{j-1});
+                           // measured equal to the fused form at n=4096 (the chip is VALU-bound
+                           // either way); default on for n >= 8192 where the fused kernel spills
 
     // profiling
     bool profiling = false;

@@ -308,6 +308,37 @@ def test_encrypt_asym_vs_oracle(env, golden, shape):
     assert V.sha256_hex(g0[0]) == g["c0_sha256"] and V.sha256_hex(g1[0]) == g["c1_sha256"]
 
 
+@pytest.mark.parametrize("shape", [(1024, 1), (4096, 3), (16384, 6)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_all_pipeline_shapes_agree(env, shape):
+    """The symmetric path has four launch shapes (aux-stream overlap on/off x fused / per-prime
+    split); all must produce the oracle's bytes."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    B = 66 if n < 16384 else 5
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=9)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n, first=31)
+    vals[1] *= 1.0e6          # a plaintext beyond 32 bits: takes the general reduction path
+    ss, sd = V.bench_seeds(B, first=31)
+    exp = [o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk) for b in range(B)]
+    for overlap in (0, 1):
+        for split in (0, 1):
+            ctx.set_pipeline(overlap, split)
+            c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+            c1 = torch.zeros_like(c0)
+            ntt_pte = torch.zeros_like(c0)
+            ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, ntt_pte)
+            torch.cuda.synchronize()
+            g0, g1, gp = host_u32(c0), host_u32(c1), host_u32(ntt_pte)
+            for b in range(B):
+                assert (g0[b] == exp[b]["c0"]).all(), (overlap, split, b)
+                assert (g1[b] == exp[b]["c1"]).all(), (overlap, split, b)
+                assert (gp[b] == exp[b]["ntt_pte"]).all(), (overlap, split, b)
+
+
 def test_encode_only_config5(env):
     from oracle.pyoracle import Oracle
     torch = env["torch"]

@@ -25,7 +25,7 @@ def timed(f, reps=3):
 print("uniform alone (bench seeds, c1 buffer): %.3f ms" % timed(lambda: ctx.sample_uniform(ss, c1)))
 print("cbd alone: %.3f ms" % timed(lambda: ctx.sample_cbd(sd, err, n // 16)))
 print("cbd+uniform back to back: %.3f ms" % timed(lambda: (ctx.sample_cbd(sd, err, n // 16), ctx.sample_uniform(ss, c1))))
-for ov, sp in ((0, 0), (1, 0), (1, 1)):
+for ov, sp in ((0, 0), (1, 0), (0, 1), (1, 1)):
     ctx.set_pipeline(ov, sp)
     print("full encrypt_sym overlap=%d split=%d: %.3f ms" % (ov, sp, timed(lambda: ctx.encrypt_sym(vals, ss, sd, c0, c1), reps=5)))
     ctx.set_profiling(True); ctx.stage_ms(True)
