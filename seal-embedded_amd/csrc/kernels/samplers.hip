@@ -62,8 +62,15 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
     constexpr int FULL_STEPS = (N * 4) / 136;            // permutations that yield 34 words
     constexpr int TAIL_WORDS = N - FULL_STEPS * 34;      // words taken from one more permutation
 
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= A.B) return;
+    // dynamic LDS: reserved (> 80 KiB) to pin one workgroup per CU; its first bytes hold the
+    // per-wave rank -> lane table of the balanced redraw phase
+    extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];
+    const int lane      = threadIdx.x & 63;
+    uint8_t *rank2lane  = pin_lds + (threadIdx.x >> 6) * 64;
+
+    const size_t bq   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = bq < A.B;          // lanes past the batch stay alive as redraw helpers
+    const size_t b    = active ? bq : (size_t)A.B - 1;
 
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
@@ -75,91 +82,125 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
         const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
         uint32_t *mypoly = A.out + (b * A.out_primes + j) * (size_t)N;
 
-        KeccakState st;
-        prng_absorb(st, seed, ctr);
-        ctr++;
         uint32_t nrej = 0;
-
-        // reject test and reduction of one word: sample.c:50-56
-        auto word = [&](uint32_t x, uint32_t idx) -> uint32_t {
-            uint32_t r = barrett32(x, q, crh);
-            if (x >= bound && !(A.debug_flags & 4))
-            {
-                if (nrej < A.rej_cap) mylist[nrej] = idx;
-                nrej++;
-                r = kRejMarker;
-            }
-            return r;
-        };
-
-        uint32_t idx = 0;
-        for (int step = 0; step < FULL_STEPS; step++)
+        if (active)
         {
-            keccak_f1600(st);
-#pragma unroll
-            for (int i = 0; i < 17; i++)
+            KeccakState st;
+            prng_absorb(st, seed, ctr);
+            ctr++;
+
+            // reject test and reduction of one word: sample.c:50-56
+            auto word = [&](uint32_t x, uint32_t idx) -> uint32_t {
+                uint32_t r = barrett32(x, q, crh);
+                if (x >= bound && !(A.debug_flags & 4))
+                {
+                    if (nrej < A.rej_cap) mylist[nrej] = idx;
+                    nrej++;
+                    r = kRejMarker;
+                }
+                return r;
+            };
+
+            uint32_t idx = 0;
+            for (int step = 0; step < FULL_STEPS; step++)
             {
-                uint32_t w0 = word(st.lo[i], idx + 2 * i);
-                uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
-                if (!(A.debug_flags & 1))
+                keccak_f1600(st);
+#pragma unroll
+                for (int i = 0; i < 17; i++)
+                {
+                    uint32_t w0 = word(st.lo[i], idx + 2 * i);
+                    uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
+                    if (!(A.debug_flags & 1))
+                        *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                    else if (w0 == 0x12345678u && w1 == 0x9abcdef0u)
+                        mypoly[0] = w0;  // keeps the values live without storing them
+                }
+                idx += 34;
+            }
+            if constexpr (TAIL_WORDS > 0)
+            {
+                keccak_f1600(st);
+#pragma unroll
+                for (int i = 0; i < TAIL_WORDS / 2; i++)
+                {
+                    uint32_t w0 = word(st.lo[i], idx + 2 * i);
+                    uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
                     *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-                else if (w0 == 0x12345678u && w1 == 0x9abcdef0u)
-                    mypoly[0] = w0;  // keeps the values live without storing them
-            }
-            idx += 34;
-        }
-        if constexpr (TAIL_WORDS > 0)
-        {
-            keccak_f1600(st);
-#pragma unroll
-            for (int i = 0; i < TAIL_WORDS / 2; i++)
-            {
-                uint32_t w0 = word(st.lo[i], idx + 2 * i);
-                uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
-                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                }
             }
         }
         // bulk stores (and list entries) must have landed before phase 2 patches / reads them
         __builtin_amdgcn_s_waitcnt(0);
         __threadfence_block();
 
-        // ---- phase 2: candidate stream for the rejected coefficients ---------------------
+        // ---- phase 2: redraws, balanced over the wave ----------------------------------------
+        // The k-th rejected coefficient takes the k-th accepted candidate of the stream
+        // block(ctr)[0:4], block(ctr+1)[0:4], ... ; a draw is consumed (counter advanced) only
+        // while the ciphertext still needs one.  Candidates are independent SHAKE calls, so lanes
+        // that are done compute candidates for lanes that are not: each round the 64 lane slots
+        // are dealt round-robin over the R needy lanes (slot s -> needy lane s % R, counter offset
+        // s / R) and every needy lane then consumes its candidates in counter order.  The wave
+        // finishes in ~ceil(total draws / 64) rounds instead of max-over-lanes draws.
+        uint32_t need    = (A.debug_flags & 2) ? 0u : nrej;
         uint32_t k       = 0;  // rejected coefficients resolved so far
-        uint32_t scanpos = 0;  // overflow path: next index to scan for a marker
-        if (A.debug_flags & 2) nrej = 0;
-        while (__any(k < nrej))
+        uint32_t scanpos = 0;  // list-overflow path: next index to scan for a marker
+        for (;;)
         {
+            const uint64_t mask = __ballot(need > 0);
+            if (mask == 0) break;
+            const uint32_t R      = (uint32_t)__popcll(mask);
+            const uint32_t myrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (need > 0) rank2lane[myrank] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t d      = (uint32_t)lane / R;          // counter offset of this slot
+            const uint32_t target = rank2lane[(uint32_t)lane - d * R];
+            __builtin_amdgcn_wave_barrier();
+
+            uint32_t tseed[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) tseed[i] = (uint32_t)__shfl((int)seed[i], (int)target);
+            const uint32_t tlo = (uint32_t)__shfl((int)(uint32_t)ctr, (int)target);
+            const uint32_t thi = (uint32_t)__shfl((int)(uint32_t)(ctr >> 32), (int)target);
             KeccakState cs;
-            prng_absorb(cs, seed, ctr);
+            prng_absorb(cs, tseed, ((((uint64_t)thi) << 32) | tlo) + d);
             keccak_f1600(cs);
-            if (k < nrej)
+            const uint32_t cand = cs.lo[0];
+
+            const uint32_t dmax = (63u / R) + 1u;  // most candidates any lane received
+            for (uint32_t dd = 0; dd < dmax; dd++)
             {
-                ctr++;
-                uint32_t x = cs.lo[0];
-                if (x < bound)
+                const uint32_t src = myrank + dd * R;
+                const uint32_t x   = (uint32_t)__shfl((int)cand, (int)(src & 63u));
+                if (need > 0 && src < 64u)
                 {
-                    uint32_t pos;
-                    if (k < A.rej_cap)
+                    ctr++;
+                    if (x < bound)
                     {
-                        pos = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        uint32_t pos;
+                        if (k < A.rej_cap)
+                        {
+                            pos = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        else
+                        {
+                            // list overflow: rejected positions are exactly the marker words
+                            pos = scanpos;
+                            while (__hip_atomic_load(mypoly + pos, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT) != kRejMarker)
+                                pos++;
+                        }
+                        scanpos     = pos + 1;
+                        mypoly[pos] = barrett32(x, q, crh);
+                        k++;
+                        need--;
                     }
-                    else
-                    {
-                        // list overflow: rejected positions are exactly the marker words
-                        pos = scanpos;
-                        while (__hip_atomic_load(mypoly + pos, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT) != kRejMarker)
-                            pos++;
-                    }
-                    scanpos     = pos + 1;
-                    mypoly[pos] = barrett32(x, q, crh);
-                    k++;
                 }
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
     }
-    if (A.ctr_out) A.ctr_out[b] = ctr;
+    if (A.ctr_out && active) A.ctr_out[b] = ctr;
 }
 
 // ------------------------------------------------------------------------------------------
