@@ -119,7 +119,7 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
 }
 
 template <int LOGN, int MODE>
-__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? 3 : 1)) void k_encode_encrypt(DevParams P, DevTables T,
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kModeAsym ? 2 : 3) : 1)) void k_encode_encrypt(DevParams P, DevTables T,
                                                                           EncArgs A)
 {
     using G            = XformGeom<LOGN>;
