@@ -124,7 +124,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK/MASTER_PORT set) always bring RCCL up, also for one rank
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -161,7 +163,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,7 +176,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -221,7 +223,7 @@ def main():
                 "pipeline_frac": bytes_per_unit * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
 
     gather = None
-    if args.gather and world > 1 and mode != "encode":
+    if args.gather and use_dist and mode != "encode":
         from seal_embedded_amd.sharding import gather_records
         fence()
         g0 = time.perf_counter()
@@ -257,7 +259,7 @@ def main():
         if gather:
             line["gather"] = gather
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
