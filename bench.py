@@ -138,10 +138,8 @@ def main():
     if mode == "sym":
         ctx.set_secret_key(sk)
     elif mode == "asym":
-        # public key from fixed seeds through the oracle's gen_pk restatement (key-side tooling is
-        # outside the timed path; the reference takes pk from files the adapter wrote)
-        from oracle.pyoracle import Oracle
-        pk0, pk1 = Oracle(n, npr).gen_pk(sk, bytes(64), bytes(range(64)))
+        # public key from fixed seeds: gen_pk on the GPU (se_amd_gen_public_key)
+        pk0, pk1 = ctx.gen_public_key(sk, bytes(64), bytes(range(64)))
         ctx.set_public_key(pk0, pk1)
 
     # ---- synthetic inputs, resident in HBM before timing; rank r owns batch block r ----------

@@ -149,6 +149,12 @@ int se_amd_index_map(const se_amd_ctx *ctx, uint16_t *map /*[n], host*/);
 int se_amd_set_secret_key(se_amd_ctx *ctx, const uint8_t *sk_packed);
 int se_amd_set_public_key(se_amd_ctx *ctx, const uint32_t *pk0, const uint32_t *pk1);
 int se_amd_load_keys_from_dir(se_amd_ctx *ctx, const char *dir, int want_pk);
+/* gen_pk (ckks_asym.c:159-171 as driven by device/test/ckks_tests_asym.c:174-208) on the GPU: ep =
+ * n CBD samples from PRNG(ep_seed); per prime the shareable PRNG restarts from pk_seed at counter 0;
+ * pk1_j = a_j, pk0_j = -(a_j . NTT(s)) + NTT(ep mod q_j).  Also installs sk in the context.
+ * Outputs [np][n] uint32 (host), the payloads of pk{0,1}_ntt_<n>_<q>.dat. */
+int se_amd_gen_public_key(se_amd_ctx *ctx, const uint8_t *sk_packed, const uint8_t *pk_seed,
+                          const uint8_t *ep_seed, uint32_t *pk0, uint32_t *pk1);
 
 /* Whole path, device pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
  * Optional outputs may be NULL: ntt_pte [B][np][n] = NTT(m+e mod q_j); pte [B][n] int64;

@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "se_cleanup", "se_encrypt_batch",
     "se_amd_create", "se_amd_destroy", "se_amd_degree", "se_amd_nprimes", "se_amd_scale",
     "se_amd_moduli", "se_amd_index_map", "se_amd_set_secret_key", "se_amd_set_public_key",
-    "se_amd_load_keys_from_dir", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device",
+    "se_amd_load_keys_from_dir", "se_amd_gen_public_key", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device",
     "se_amd_encode_ntt_device", "se_amd_encrypt_sym_host", "se_amd_encrypt_asym_host",
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
@@ -79,6 +79,7 @@ def lib():
     L.se_amd_set_secret_key.argtypes = [vp, vp]
     L.se_amd_set_public_key.argtypes = [vp, vp, vp]
     L.se_amd_load_keys_from_dir.argtypes = [vp, C.c_char_p, i32]
+    L.se_amd_gen_public_key.argtypes = [vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_sym_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_asym_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encode_ntt_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
@@ -173,6 +174,17 @@ class Context:
         pk1 = np.ascontiguousarray(pk1, dtype=np.uint32)
         assert pk0.size == self.np * self.n == pk1.size
         _check(self.L.se_amd_set_public_key(self.h, _ptr(pk0), _ptr(pk1)), "se_amd_set_public_key")
+
+    def gen_public_key(self, sk_packed, pk_seed, ep_seed):
+        import numpy as np
+        sk = np.ascontiguousarray(sk_packed, dtype=np.uint8)
+        s1 = np.frombuffer(bytes(pk_seed), dtype=np.uint8).copy()
+        s2 = np.frombuffer(bytes(ep_seed), dtype=np.uint8).copy()
+        pk0 = np.zeros((self.np, self.n), dtype=np.uint32)
+        pk1 = np.zeros_like(pk0)
+        _check(self.L.se_amd_gen_public_key(self.h, _ptr(sk), _ptr(s1), _ptr(s2), _ptr(pk0),
+                                            _ptr(pk1)), "se_amd_gen_public_key")
+        return pk0, pk1
 
     def load_keys_from_dir(self, path, want_pk=False):
         _check(self.L.se_amd_load_keys_from_dir(self.h, path.encode(), 1 if want_pk else 0),

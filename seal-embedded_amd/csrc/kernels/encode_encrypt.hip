@@ -380,6 +380,28 @@ __global__ void k_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, 
     }
 }
 
+// reduce_set_e_small (ckks_common.c:259-265) for every prime: int8 error -> residues, natural order,
+// into a [count][np][n] slab (public-key generation feeds them to k_ntt_fuse).
+__global__ void k_reduce_small(DevParams P, const int8_t *e, uint32_t *out, int count)
+{
+    const int n = P.n, np = P.nprimes;
+    size_t i    = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)count * n) return;
+    size_t b = i / n, k = i - b * n;
+    int32_t v = e[i];
+    for (int j = 0; j < np; j++) out[(b * np + j) * n + k] = (v < 0 ? P.q[j] : 0u) + (uint32_t)v;
+}
+
+hipError_t launch_reduce_small(const DevParams &P, const int8_t *e, uint32_t *out, size_t count,
+                               hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    size_t total = count * P.n;
+    hipLaunchKernelGGL(k_reduce_small, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, e, out,
+                       (int)count);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers (called from se_context.cpp)
 // ------------------------------------------------------------------------------------------

@@ -56,6 +56,7 @@ hipError_t launch_encode_rns(const DevParams &, const DevTables &, const EncArgs
                              size_t B, hipStream_t);
 hipError_t launch_ntt_fuse(const DevParams &, const DevTables &, const EncArgs &, int mode, int j,
                            size_t B, hipStream_t);
+hipError_t launch_reduce_small(const DevParams &, const int8_t *e, uint32_t *out, size_t count, hipStream_t);
 hipError_t launch_ntt_polys(const DevParams &, const DevTables &, int j, uint32_t *polys,
                             uint32_t *pairs, size_t count, hipStream_t);
 hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, size_t count,

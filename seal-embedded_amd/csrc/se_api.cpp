@@ -80,6 +80,13 @@ int se_amd_set_public_key(se_amd_ctx *ctx, const uint32_t *pk0, const uint32_t *
     return ctx->c.set_public_key(pk0, pk1);
 }
 
+int se_amd_gen_public_key(se_amd_ctx *ctx, const uint8_t *sk_packed, const uint8_t *pk_seed,
+                          const uint8_t *ep_seed, uint32_t *pk0, uint32_t *pk1)
+{
+    if (!ctx || !sk_packed || !pk_seed || !ep_seed || !pk0 || !pk1) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.gen_public_key(sk_packed, pk_seed, ep_seed, pk0, pk1);
+}
+
 static int read_exact(const std::string &path, void *dst, size_t bytes)
 {
     FILE *f = fopen(path.c_str(), "rb");

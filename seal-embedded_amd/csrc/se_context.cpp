@@ -181,6 +181,43 @@ int Context::set_public_key(const uint32_t *pk0, const uint32_t *pk1)
     return 0;
 }
 
+// gen_pk (ckks_asym.c:159-171, driven as device/test/ckks_tests_asym.c:174-208 does): the public
+// key is a symmetric encryption of zero with a small error:  pk1_j = a_j (shareable PRNG re-seeded
+// with pk_seed at counter 0 for EVERY prime), pk0_j = -(a_j . NTT(s)) + NTT(ep mod q_j), ep = n CBD
+// samples from PRNG(ep_seed).  Built from the path's own kernels.
+int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, const uint8_t *ep_seed,
+                            uint32_t *pk0_out, uint32_t *pk1_out)
+{
+    int rc = set_secret_key(sk_packed);
+    if (rc) return rc;
+    rc = ensure_scratch(1);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
+    uint8_t *d_seeds = nullptr;
+    uint32_t *d_c    = nullptr;  // [2][np][n]: residues/pk0 then a/pk1
+    SEAMD_HIP(hipMalloc((void **)&d_seeds, 128));
+    SEAMD_HIP(hipMalloc((void **)&d_c, (size_t)2 * np * n * sizeof(uint32_t)));
+    SEAMD_HIP(hipMemcpy(d_seeds, ep_seed, 64, hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_seeds + 64, pk_seed, 64, hipMemcpyHostToDevice));
+    uint32_t *d_p0 = d_c, *d_p1 = d_c + (size_t)np * n;
+    CbdArgs ca{d_seeds, nullptr, d_err, n / 16, 1};
+    SEAMD_HIP(launch_sample_cbd(ca, nullptr));
+    SEAMD_HIP(launch_reduce_small(dp, d_err, d_p0, 1, nullptr));
+    EncArgs ea{nullptr, nullptr, nullptr, d_p0, d_p1, nullptr, nullptr, nullptr};
+    for (uint32_t j = 0; j < np; j++)
+    {
+        UniformArgs ua{d_seeds + 64, nullptr, nullptr, d_p1, d_rej, rej_cap, 1, j, j + 1, np, 0};
+        SEAMD_HIP(launch_sample_uniform(dp, ua, nullptr));
+        SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, 1, nullptr));
+    }
+    SEAMD_HIP(hipDeviceSynchronize());
+    SEAMD_HIP(hipMemcpy(pk0_out, d_p0, (size_t)np * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SEAMD_HIP(hipMemcpy(pk1_out, d_p1, (size_t)np * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SEAMD_HIP(hipFree(d_seeds));
+    SEAMD_HIP(hipFree(d_c));
+    return 0;
+}
+
 void Context::stage_begin(int stage, hipStream_t st)
 {
     if (!profiling) return;

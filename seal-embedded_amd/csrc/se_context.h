@@ -66,6 +66,8 @@ struct Context
     int ensure_scratch(size_t B);
     int set_secret_key(const uint8_t *sk_packed);
     int set_public_key(const uint32_t *pk0, const uint32_t *pk1);
+    int gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, const uint8_t *ep_seed,
+                       uint32_t *pk0_out, uint32_t *pk1_out);
 
     int encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share_seeds,
                     const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,

@@ -339,6 +339,20 @@ def test_all_pipeline_shapes_agree(env, shape):
                 assert (gp[b] == exp[b]["ntt_pte"]).all(), (overlap, split, b)
 
 
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_gen_public_key_vs_reference_golden(env, golden, shape):
+    """gen_pk on the GPU equals the compiled reference's gen_pk (golden digests) and the oracle."""
+    from oracle.pyoracle import Oracle
+    n, npr = shape
+    g = golden["digests"]["shapes"][f"{n}x{npr}"]["asym_survey"]
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    pk0, pk1 = ctx.gen_public_key(sk, SEED_PK, SEED_EP)
+    assert V.sha256_hex(pk0) == g["pk0_sha256"] and V.sha256_hex(pk1) == g["pk1_sha256"]
+    o0, o1 = Oracle(n, npr).gen_pk(sk, SEED_PK, SEED_EP)
+    assert (pk0 == o0).all() and (pk1 == o1).all()
+
+
 def test_encode_only_config5(env):
     from oracle.pyoracle import Oracle
     torch = env["torch"]
