@@ -203,6 +203,24 @@ int se_amd_sample_cbd_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint
                              size_t B, size_t blocks_per_ct, int8_t *d_out, void *stream);
 void se_amd_pack_ternary_host(const int8_t *codes, size_t n, uint8_t *packed /*[n/4]*/);
 
+/* ---- formats on either side of the path (host only) ---------------------------------------- */
+/* SEAL Ciphertext data of size 2 (adapter/fileops.cpp:515-527): out[i + j*n] = c0 prime j,
+ * out[i + j*n + np*n] = c1 prime j, one uint64 per coefficient; out has 2*np*n entries. */
+void se_amd_pack_seal_ciphertext_host(const uint32_t *c0, const uint32_t *c1, size_t n, size_t np,
+                                      uint64_t *out);
+/* print_poly_full / print_poly_flpt_full text lines (util_print.h:229-245,491-508):
+ * "name : { v0, v1, ... }\n".  Return the length needed (excluding the NUL); write at most cap. */
+size_t se_amd_format_poly_text(const char *name, const uint32_t *poly, size_t n, char *buf, size_t cap);
+size_t se_amd_format_values_text(const char *name, const float *v, size_t len, char *buf, size_t cap);
+/* One ciphertext as the adapter's verify path reads it (api_tests.c:30-42,75-90): optional
+ * "v (cleartext)" line, then "c0" and "c1" lines per prime. */
+int se_amd_write_ciphertext_text(const char *path, int append, const float *values, size_t vlen,
+                                 const uint32_t *c0, const uint32_t *c1, size_t n, size_t np);
+/* key files in the device-side formats (fileops.c:140-204) */
+int se_amd_save_secret_key_file(const char *dir, size_t n, const uint8_t *sk_packed);
+int se_amd_save_public_key_files(const char *dir, size_t n, size_t np, const uint32_t *q,
+                                 const uint32_t *pk0, const uint32_t *pk1);
+
 /* ---- profiling hooks ---------------------------------------------------------------------- */
 /* When enabled, every kernel launched by the whole-path entries is bracketed by HIP events on the
  * caller's stream; after a stream sync se_amd_stage_ms returns the accumulated milliseconds and

@@ -348,6 +348,7 @@ class Reference:
             L.refh_api_encrypt.restype = C.c_long
             L.refh_api_encrypt.argtypes = [C.c_size_t, C.c_size_t, C.c_int, f32p, C.c_size_t, u8p,
                                            u8p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+            L.refh_print_to_file.argtypes = [C.c_char_p, C.c_char_p, u32p, C.c_size_t, f32p, C.c_size_t]
             L.refh_encrypt_sym_batch.restype = C.c_int
             L.refh_encrypt_sym_batch.argtypes = [C.c_size_t, C.c_size_t, f32p, C.c_size_t, u8p,
                                                  u8p, u8p, u32p, u32p, C.c_int]
@@ -497,6 +498,15 @@ class Reference:
                                       _p(pk0, u32p), _p(pk1, u32p), _p(c0, u32p), _p(c1, u32p),
                                       _p(pte, i64p), _p(u, u8p), _p(e1, i8p), C.byref(ctr))
         return dict(ok=bool(ok), c0=c0, c1=c1, pte=pte, u=u, e1=e1, end_ctr=int(ctr.value))
+
+    @classmethod
+    def print_text(cls, path, name, poly=None, values=None):
+        """The reference's print_poly_flpt_full / print_poly_full output, captured into `path`."""
+        L = cls.lib()
+        p = None if poly is None else np.ascontiguousarray(poly, dtype=np.uint32)
+        v = None if values is None else np.ascontiguousarray(values, dtype=np.float32)
+        L.refh_print_to_file(path.encode(), name.encode(), _p(p, u32p), 0 if p is None else p.size,
+                             _p(v, f32p), 0 if v is None else v.size)
 
     @classmethod
     def gen_pk(cls, n, nprimes, sk_packed, pk_seed, ep_seed):

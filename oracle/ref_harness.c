@@ -33,6 +33,7 @@
 #include "sample.h"
 #include "seal_embedded.h"
 #include "uintmodarith.h"
+#include "util_print.h"
 
 /* The reference prints unconditionally (ckks_sym.c:153-155, seal_embedded.c:48).  Silence
  * stdout around calls so pytest / bench output stays clean. */
@@ -439,4 +440,20 @@ int refh_encrypt_sym_batch(size_t n, size_t nprimes, const float *values, size_t
     free(th);
     free(jobs);
     return 1;
+}
+
+/* --- the reference's own text printers, captured into a file (format pin for se_formats.cpp) --- */
+void refh_print_to_file(const char *path, const char *name, const uint32_t *poly, size_t n,
+                        const float *values, size_t vlen)
+{
+    fflush(stdout);
+    int saved = dup(1);
+    int fd    = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    dup2(fd, 1);
+    close(fd);
+    if (values) print_poly_flpt_full("v (cleartext)", values, vlen);
+    if (poly) print_poly_full(name, poly, n);
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
 }

@@ -47,7 +47,9 @@ EXPORTED_SYMBOLS = (
     "se_amd_encode_ntt_device", "se_amd_encrypt_sym_host", "se_amd_encrypt_asym_host",
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
-    "se_amd_pack_ternary_host", "se_amd_set_profiling", "se_amd_stage_ms",
+    "se_amd_pack_ternary_host", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
+    "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
+    "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
     "se_amd_set_reject_list_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
 )
 
@@ -93,6 +95,15 @@ def lib():
     L.se_amd_sample_cbd_device.argtypes = [vp, vp, vp, sz, sz, vp, vp]
     L.se_amd_pack_ternary_host.argtypes = [vp, sz, vp]
     L.se_amd_pack_ternary_host.restype = None
+    L.se_amd_pack_seal_ciphertext_host.argtypes = [vp, vp, sz, sz, vp]
+    L.se_amd_pack_seal_ciphertext_host.restype = None
+    L.se_amd_format_poly_text.argtypes = [C.c_char_p, vp, sz, vp, sz]
+    L.se_amd_format_poly_text.restype = sz
+    L.se_amd_format_values_text.argtypes = [C.c_char_p, vp, sz, vp, sz]
+    L.se_amd_format_values_text.restype = sz
+    L.se_amd_write_ciphertext_text.argtypes = [C.c_char_p, i32, vp, sz, vp, vp, sz, sz]
+    L.se_amd_save_secret_key_file.argtypes = [C.c_char_p, sz, vp]
+    L.se_amd_save_public_key_files.argtypes = [C.c_char_p, sz, sz, vp, vp, vp]
     L.se_amd_set_profiling.argtypes = [vp, i32]
     L.se_amd_stage_ms.argtypes = [vp, vp, vp, i32]
     L.se_amd_set_reject_list_capacity.argtypes = [vp, u32]

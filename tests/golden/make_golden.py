@@ -193,6 +193,16 @@ def main():
         R.close()
         print("done", n, nprimes, d["api_fnv1a64_sym"], d["api_fnv1a64_asym"])
 
+    # ---- text format of util_print.h (print_poly_full / print_poly_flpt_full) -----------------
+    poly = np.array([0, 1, 134012928, 1053818880, 4294967295, 7, 65536, 123456789], dtype=np.uint32)
+    vals = np.array([0.0, 1.0, -2.1, 1.1, 0.005, -0.005, 25.5, -100.125, 3.14159, 1e6], dtype=np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        f1, f2 = os.path.join(td, "p.txt"), os.path.join(td, "v.txt")
+        Reference.print_text(f1, "c0", poly=poly)
+        Reference.print_text(f2, "x", values=vals)
+        digests["text_format"] = {"poly": [int(x) for x in poly], "values": [float(x) for x in vals],
+                                  "poly_line": open(f1).read(), "values_line": open(f2).read()}
+
     np.savez_compressed(os.path.join(HERE, "golden_c1.npz"), **small)
     with open(os.path.join(HERE, "golden_digests.json"), "w") as f:
         json.dump(digests, f, indent=1, sort_keys=True)
