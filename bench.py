@@ -53,23 +53,34 @@ def cpu_baseline(n, npr, mode, budget_s=12.0):
     import numpy as np
     import vectors as V
     from oracle import pyoracle
-    cores = os.cpu_count() or 1
+    # host threads we may really use: affinity mask, clipped by the cgroup CPU quota if one is set
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except Exception:
+        pass
     sk = V.secret_key(n)
     use_ref = pyoracle.ref_available()
     kind = "reference" if use_ref else "port"
     if mode != "sym":
         use_ref, kind = False, "port"   # batched reference driver exists for the symmetric path
 
-    def run(B):
+    def run(B, nthreads=None):
+        nthreads = nthreads or cores
         vals = V.bench_values(B, n)
         ss, sd = V.bench_seeds(B)
         t0 = time.perf_counter()
         if mode == "sym":
             if use_ref:
-                pyoracle.Reference.encrypt_sym_batch(n, npr, vals, ss, sd, sk, nthreads=cores,
+                pyoracle.Reference.encrypt_sym_batch(n, npr, vals, ss, sd, sk, nthreads=nthreads,
                                                      keep=False)
             else:
-                pyoracle.Oracle(n, npr).encrypt_sym_batch(vals, ss, sd, sk, nthreads=cores,
+                pyoracle.Oracle(n, npr).encrypt_sym_batch(vals, ss, sd, sk, nthreads=nthreads,
                                                           keep=False)
         else:
             o = pyoracle.Oracle(n, npr)
@@ -90,11 +101,15 @@ def cpu_baseline(n, npr, mode, budget_s=12.0):
     B = int(max(probe, min(200000, probe * budget_s / max(t, 1e-6))))
     B = max(threads, (B // threads) * threads)
     t = run(B)
+    one = None
+    if mode == "sym":
+        b1 = max(8, int(2.0 * B / t / threads))      # ~2 s on one thread
+        one = b1 / run(b1, nthreads=1)
     return {"value": B / t, "unit": "ciphertexts/s" if mode != "encode" else "plaintexts/s",
             "cores": threads, "kind": kind,
             "sample": f"{B} units of the same synthetic workload in {t:.2f} s on {threads} host "
                       f"thread(s); {'oracle/_ref (compiled reference, -O3 -fno-strict-aliasing)' if use_ref else 'oracle/se_oracle.c (C restatement, -O2)'}",
-            "single_core_est": B / t / threads}
+            "single_thread_value": one}
 
 
 def main():
