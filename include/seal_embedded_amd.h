@@ -186,6 +186,16 @@ int se_amd_encode_device(se_amd_ctx *ctx, const float *d_values, size_t B, int64
                          uint8_t *d_status, void *stream);
 /* ntt_inpl (ntt.c:168-189) for prime j on `count` polynomials [count][n], in place. */
 int se_amd_ntt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t count, void *stream);
+/* intt_inpl (intt.c:144-222, test-side in the reference) for prime j on `count` polynomials
+ * [count][n], in place: NTT-form bit-reversed in, natural-order canonical out. */
+int se_amd_intt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t count, void *stream);
+/* The reference's round-trip check, batched (device/test/ckks_tests_common.c:59-231): for prime j
+ * of every ciphertext d = c0 + c1 . NTT(s) (ckks_decrypt), pt = INTT(d), values = ckks_decode(pt).
+ * Optional outputs (NULL to skip): d_dec_ntt [B][n], d_pt [B][n] uint32, d_values [B][n/2] float.
+ * For a symmetric ciphertext d_dec_ntt equals NTT(m+e mod q_j) exactly. */
+int se_amd_decrypt_decode_device(se_amd_ctx *ctx, const uint32_t *d_c0, const uint32_t *d_c1,
+                                 size_t B, size_t prime, uint32_t *d_dec_ntt, uint32_t *d_pt,
+                                 float *d_values, void *stream);
 /* prng_fill_buffer (rng.h:78-91): out[i] = SHAKE256(seed[i] || le64(ctr[i]))[0:outlen]. */
 int se_amd_prng_blocks_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctrs,
                               uint8_t *d_out, size_t outlen, size_t count, void *stream);

@@ -93,6 +93,10 @@ class Oracle:
             L.seo_ntt_inpl.argtypes = [C.POINTER(SeoParams), C.c_size_t, u32p, u32p]
             L.seo_reduce_pte.argtypes = [C.POINTER(SeoParams), C.c_size_t, i64p, u32p]
             L.seo_reduce_e_small.argtypes = [C.POINTER(SeoParams), C.c_size_t, i8p, u32p]
+            L.seo_intt_inpl.argtypes = [C.POINTER(SeoParams), C.c_size_t, u32p]
+            L.seo_fft_inpl.argtypes = [f64p, C.c_size_t, C.c_size_t]
+            L.seo_decrypt.argtypes = [C.POINTER(SeoParams), C.c_size_t, u32p, u32p, u32p, u32p]
+            L.seo_decode.argtypes = [C.POINTER(SeoParams), C.c_size_t, u16p, u32p, C.c_size_t, f32p]
             L.seo_encrypt_sym.restype = C.c_int
             L.seo_encrypt_sym.argtypes = [C.POINTER(SeoParams), u16p, f32p, C.c_size_t, u8p, u8p,
                                           u8p, u32p, u32p, i64p, u32p, u64p]
@@ -234,6 +238,33 @@ class Oracle:
         self.L.seo_reduce_e_small(C.byref(self.p), j, _p(ein, i8p), _p(out, u32p))
         return out
 
+    # -- verification side
+    def intt(self, vec, j):
+        v = np.array(vec, dtype=np.uint32).copy()
+        self.L.seo_intt_inpl(C.byref(self.p), j, _p(v, u32p))
+        return v
+
+    def fft(self, x_complex):
+        x = np.ascontiguousarray(np.asarray(x_complex, dtype=np.complex128)).view(np.float64).copy()
+        self.L.seo_fft_inpl(_p(x, f64p), self.n, self.logn)
+        return x.view(np.complex128)
+
+    def decrypt(self, c0, c1, ntt_s, j):
+        a = np.ascontiguousarray(c0, dtype=np.uint32)
+        b = np.ascontiguousarray(c1, dtype=np.uint32)
+        s = np.ascontiguousarray(ntt_s, dtype=np.uint32)
+        out = np.zeros(self.n, dtype=np.uint32)
+        self.L.seo_decrypt(C.byref(self.p), j, _p(a, u32p), _p(b, u32p), _p(s, u32p), _p(out, u32p))
+        return out
+
+    def decode(self, pt, j, values_len=None):
+        values_len = self.n // 2 if values_len is None else values_len
+        x = np.ascontiguousarray(pt, dtype=np.uint32)
+        out = np.zeros(values_len, dtype=np.float32)
+        self.L.seo_decode(C.byref(self.p), j, _p(self.map, u16p), _p(x, u32p), values_len,
+                          _p(out, f32p))
+        return out
+
     # -- whole path
     def encrypt_sym(self, values, share_seed, seed, sk_packed):
         v = np.ascontiguousarray(values, dtype=np.float32).ravel()
@@ -348,6 +379,9 @@ class Reference:
             L.refh_api_encrypt.restype = C.c_long
             L.refh_api_encrypt.argtypes = [C.c_size_t, C.c_size_t, C.c_int, f32p, C.c_size_t, u8p,
                                            u8p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+            L.refh_intt.argtypes = [C.c_void_p, C.c_size_t, u32p]
+            L.refh_decrypt.argtypes = [C.c_void_p, C.c_size_t, u32p, u32p, u32p, u32p]
+            L.refh_decode.argtypes = [C.c_void_p, C.c_size_t, u32p, C.c_size_t, f32p]
             L.refh_print_to_file.argtypes = [C.c_char_p, C.c_char_p, u32p, C.c_size_t, f32p, C.c_size_t]
             L.refh_encrypt_sym_batch.restype = C.c_int
             L.refh_encrypt_sym_batch.argtypes = [C.c_size_t, C.c_size_t, f32p, C.c_size_t, u8p,
@@ -458,6 +492,26 @@ class Reference:
         ein = np.ascontiguousarray(e, dtype=np.int8)
         out = np.zeros(self.n, dtype=np.uint32)
         self.L.refh_reduce_e_small(self.h, j, _p(ein, i8p), _p(out, u32p))
+        return out
+
+    def intt(self, vec, j):
+        v = np.array(vec, dtype=np.uint32).copy()
+        self.L.refh_intt(self.h, j, _p(v, u32p))
+        return v
+
+    def decrypt(self, c0, c1, ntt_s, j):
+        a = np.ascontiguousarray(c0, dtype=np.uint32)
+        b = np.ascontiguousarray(c1, dtype=np.uint32)
+        s = np.ascontiguousarray(ntt_s, dtype=np.uint32)
+        out = np.zeros(self.n, dtype=np.uint32)
+        self.L.refh_decrypt(self.h, j, _p(a, u32p), _p(b, u32p), _p(s, u32p), _p(out, u32p))
+        return out
+
+    def decode(self, pt, j, values_len=None):
+        values_len = self.n // 2 if values_len is None else values_len
+        x = np.ascontiguousarray(pt, dtype=np.uint32)
+        out = np.zeros(values_len, dtype=np.float32)
+        self.L.refh_decode(self.h, j, _p(x, u32p), values_len, _p(out, f32p))
         return out
 
     def barrett32(self, x, j=0):

@@ -34,6 +34,8 @@
 #include "seal_embedded.h"
 #include "uintmodarith.h"
 #include "util_print.h"
+#include "intt.h"
+#include "ckks_tests_common.h"
 
 /* The reference prints unconditionally (ckks_sym.c:153-155, seal_embedded.c:48).  Silence
  * stdout around calls so pytest / bench output stays clean. */
@@ -456,4 +458,38 @@ void refh_print_to_file(const char *path, const char *name, const uint32_t *poly
     fflush(stdout);
     dup2(saved, 1);
     close(saved);
+}
+
+/* --- verification side: the reference's own test helpers (device/test/ckks_tests_common.c) ---- */
+void refh_intt(void *vh, size_t j, uint32_t *vec)
+{
+    refh *h  = (refh *)vh;
+    size_t n = h->parms.coeff_count;
+    set_prime(h, j);
+    hush();
+    ZZ *roots = (ZZ *)malloc(n * sizeof(ZZ));
+    intt_roots_initialize(&h->parms, roots);
+    intt_inpl(&h->parms, roots, vec);
+    free(roots);
+    unhush();
+}
+
+void refh_decrypt(void *vh, size_t j, const uint32_t *c0, const uint32_t *c1, const uint32_t *ntt_s,
+                  uint32_t *out)
+{
+    refh *h = (refh *)vh;
+    set_prime(h, j);
+    ckks_decrypt(c0, c1, ntt_s, false, &h->parms, out);
+}
+
+void refh_decode(void *vh, size_t j, const uint32_t *pt, size_t values_len, float *out)
+{
+    refh *h  = (refh *)vh;
+    size_t n = h->parms.coeff_count;
+    set_prime(h, j);
+    hush();
+    double complex *tmp = (double complex *)calloc(n, sizeof(double complex));
+    ckks_decode(pt, values_len, h->ptrs.index_map_ptr, &h->parms, tmp, out);
+    free(tmp);
+    unhush();
 }

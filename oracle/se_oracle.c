@@ -664,6 +664,102 @@ void seo_gen_pk(const seo_params *p, const uint8_t *sk_packed, const uint8_t pk_
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Verification side: inverse NTT, forward FFT, pseudo-decrypt, decode
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t pow_mod(uint32_t base, uint64_t e, const seo_params *p, size_t j)
+{
+    uint32_t r = 1;
+    while (e)
+    {
+        if (e & 1) r = seo_mul_mod(r, base, p, j);
+        base = seo_mul_mod(base, base, p, j);
+        e >>= 1;
+    }
+    return r;
+}
+
+/* intt.c:144-222: Gentleman-Sande rounds tt = 1,2,..,n/4 with s = psi^-bitrev(h+j); the last
+ * round is merged with the 1/n scaling: (u+v)*inv_n, (u-v)*last_inv_sn. */
+void seo_intt_inpl(const seo_params *p, size_t j, uint32_t *vec)
+{
+    size_t n = p->n, logn = p->logn;
+    uint32_t q        = p->q[j];
+    uint32_t inv_psi  = pow_mod(p->psi[j], (uint64_t)q - 2, p, j);
+    uint32_t inv_n    = pow_mod((uint32_t)(n % q), (uint64_t)q - 2, p, j);
+    size_t tt = 1, h = n / 2;
+    for (size_t r = 0; r + 1 < logn; r++, tt *= 2, h /= 2)
+    {
+        for (size_t g = 0, k0 = 0; g < h; g++, k0 += 2 * tt)
+        {
+            uint32_t s = pow_mod(inv_psi, seo_bitrev(h + g, logn), p, j);
+            for (size_t k = k0; k < k0 + tt; k++)
+            {
+                uint32_t u = vec[k], v = vec[k + tt];
+                vec[k]      = seo_add_mod(u, v, q);
+                vec[k + tt] = seo_mul_mod(seo_sub_mod(u, v, q), s, p, j);
+            }
+        }
+    }
+    /* h == 1 here: s_last = psi^-bitrev(1) = psi^-(n/2); last_inv_sn = s_last * inv_n */
+    uint32_t last_inv_sn = seo_mul_mod(pow_mod(inv_psi, n / 2, p, j), inv_n, p, j);
+    for (size_t i = 0; i < n / 2; i++)
+    {
+        uint32_t u = vec[i], v = vec[i + n / 2];
+        vec[i]         = seo_mul_mod(seo_add_mod(u, v, q), inv_n, p, j);
+        vec[i + n / 2] = seo_mul_mod(seo_sub_mod(u, v, q), last_inv_sn, p, j);
+    }
+}
+
+/* fft.c:146-213; roots = conj of the cached IFFT table (cos, +sin) */
+void seo_fft_inpl(double *x, size_t n, size_t logn)
+{
+    const double *w = twiddles_for(n, logn);
+    for (size_t h = 1, tt = n / 2; h < n; h *= 2, tt /= 2)
+    {
+        for (size_t g = 0, k0 = 0; g < h; g++, k0 += 2 * tt)
+        {
+            double c = w[2 * (h + g)], d = -w[2 * (h + g) + 1];
+            for (size_t k = k0; k < k0 + tt; k++)
+            {
+                double ur = x[2 * k], ui = x[2 * k + 1];
+                double a = x[2 * (k + tt)], b = x[2 * (k + tt) + 1];
+                double vr = a * c - b * d, vi = a * d + b * c;
+                x[2 * k]            = ur + vr;
+                x[2 * k + 1]        = ui + vi;
+                x[2 * (k + tt)]     = ur - vr;
+                x[2 * (k + tt) + 1] = ui - vi;
+            }
+        }
+    }
+}
+
+/* device/test/ckks_tests_common.c:136-153 */
+void seo_decrypt(const seo_params *p, size_t j, const uint32_t *c0, const uint32_t *c1,
+                 const uint32_t *ntt_s, uint32_t *out)
+{
+    for (size_t i = 0; i < p->n; i++)
+        out[i] = seo_add_mod(seo_mul_mod(c1[i], ntt_s[i], p, j), c0[i], p->q[j]);
+}
+
+/* device/test/ckks_tests_common.c:59-115 */
+void seo_decode(const seo_params *p, size_t j, const uint16_t *map, const uint32_t *pt,
+                size_t values_len, float *out)
+{
+    size_t n   = p->n;
+    uint32_t q = p->q[j];
+    double *x  = (double *)calloc(2 * n, sizeof(double));
+    for (size_t i = 0; i < n; i++)
+    {
+        uint32_t val = pt[i];
+        double dval  = (val > q / 2) ? -(double)(q - val) : (double)val;
+        x[2 * i]     = dval / p->scale;
+    }
+    seo_fft_inpl(x, n, p->logn);
+    for (size_t i = 0; i < values_len; i++) out[i] = (float)x[2 * map[i]];
+    free(x);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Batched driver for the timed CPU baseline: contiguous shards, one pthread each.
  * ---------------------------------------------------------------------------------------- */
 typedef struct

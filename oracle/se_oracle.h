@@ -108,6 +108,19 @@ int seo_encrypt_asym(const seo_params *p, const uint16_t *map, const float *valu
 void seo_gen_pk(const seo_params *p, const uint8_t *sk_packed, const uint8_t pk_seed[64],
                 const uint8_t ep_seed[64], uint32_t *pk0, uint32_t *pk1);
 
+/* ---- verification side: what the reference's round-trip tests use ---- */
+/* intt_inpl (intt.c:26-58,144-222 + the inv_n / last_inv_sn constants of :230-420, which are
+ * n^-1 and (s_last * n)^-1 mod q): exact inverse of seo_ntt_inpl. */
+void seo_intt_inpl(const seo_params *p, size_t j, uint32_t *vec);
+/* fft_inpl (fft.c:146-213): rounds h = 1,2,..,n/2; (u, v) -> (u + v*s, u - v*s), s = e^{2 pi i bitrev(h+j)/2n} */
+void seo_fft_inpl(double *x_re_im, size_t n, size_t logn);
+/* ckks_decrypt (device/test/ckks_tests_common.c:136-153): out = c0 + c1 . ntt_s mod q_j */
+void seo_decrypt(const seo_params *p, size_t j, const uint32_t *c0, const uint32_t *c1,
+                 const uint32_t *ntt_s, uint32_t *out);
+/* ckks_decode (device/test/ckks_tests_common.c:59-115): centred lift, / scale, fft, slot pick */
+void seo_decode(const seo_params *p, size_t j, const uint16_t *map, const uint32_t *pt,
+                size_t values_len, float *out);
+
 /* Batched drivers used for the timed CPU baseline (one thread each; caller shards). */
 int seo_encrypt_sym_batch(const seo_params *p, const float *values /*[B][n/2]*/, size_t B,
                           const uint8_t *share_seeds /*[B][64]*/, const uint8_t *seeds /*[B][64]*/,

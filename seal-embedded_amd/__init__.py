@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_moduli", "se_amd_index_map", "se_amd_set_secret_key", "se_amd_set_public_key",
     "se_amd_load_keys_from_dir", "se_amd_gen_public_key", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device",
     "se_amd_encode_ntt_device", "se_amd_encrypt_sym_host", "se_amd_encrypt_asym_host",
-    "se_amd_encode_device", "se_amd_ntt_device", "se_amd_prng_blocks_device",
+    "se_amd_encode_device", "se_amd_ntt_device", "se_amd_intt_device", "se_amd_decrypt_decode_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
     "se_amd_pack_ternary_host", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
@@ -89,6 +89,8 @@ def lib():
     L.se_amd_encrypt_asym_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.se_amd_encode_device.argtypes = [vp, vp, sz, vp, vp, vp]
     L.se_amd_ntt_device.argtypes = [vp, sz, vp, sz, vp]
+    L.se_amd_intt_device.argtypes = [vp, sz, vp, sz, vp]
+    L.se_amd_decrypt_decode_device.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp]
     L.se_amd_prng_blocks_device.argtypes = [vp, vp, vp, vp, sz, sz, vp]
     L.se_amd_sample_uniform_device.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     L.se_amd_sample_ternary_device.argtypes = [vp, vp, sz, vp, vp, vp]
@@ -230,6 +232,17 @@ class Context:
         count = polys.numel() // self.n
         _check(self.L.se_amd_ntt_device(self.h, prime, _ptr(polys), count, _stream_ptr()),
                "se_amd_ntt_device")
+
+    def intt(self, prime, polys):
+        count = polys.numel() // self.n
+        _check(self.L.se_amd_intt_device(self.h, prime, _ptr(polys), count, _stream_ptr()),
+               "se_amd_intt_device")
+
+    def decrypt_decode(self, c0, c1, prime, dec_ntt=None, pt=None, values=None):
+        B = c0.shape[0]
+        _check(self.L.se_amd_decrypt_decode_device(self.h, _ptr(c0), _ptr(c1), B, prime,
+                                                   _ptr(dec_ntt), _ptr(pt), _ptr(values),
+                                                   _stream_ptr()), "se_amd_decrypt_decode_device")
 
     def prng_blocks(self, seeds, ctrs, out, outlen):
         _check(self.L.se_amd_prng_blocks_device(self.h, _ptr(seeds), _ptr(ctrs), _ptr(out), outlen,

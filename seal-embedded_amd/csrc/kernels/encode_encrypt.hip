@@ -380,6 +380,119 @@ __global__ void k_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Verification side: the reference's round-trip check, batched.
+//   ckks_decrypt   device/test/ckks_tests_common.c:136-153   d = c0 + c1 . NTT(s)
+//   intt_inpl      device/lib/intt.c:144-222 (+ n^-1)        pt = INTT(d)
+//   ckks_decode    device/test/ckks_tests_common.c:59-115    centred lift, / scale, fft_inpl
+//                  (device/lib/fft.c:146-213), slot pick through the index map
+// One workgroup per ciphertext, one prime per launch.  Decode is bit-exact with the reference's
+// (same butterflies, same root table, IEEE division and float conversion).
+// ------------------------------------------------------------------------------------------
+struct VerifyArgs
+{
+    const uint32_t *c0;   // [B][np][n]
+    const uint32_t *c1;   // [B][np][n]   (NULL: c0 slab already holds the value to invert)
+    uint32_t *dec_ntt;    // optional [B][n]: c0 + c1 . NTT(s) mod q_j   (NTT form)
+    uint32_t *pt;         // optional [B][n]: INTT of it, canonical, natural order
+    float *values;        // optional [B][n/2]: decoded slots
+    uint32_t in_primes;   // polynomials per record in c0/c1 (np, or 1 for a bare polynomial batch)
+    int j;                // prime
+};
+
+template <int LOGN>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_decrypt_decode(DevParams P, DevTables T,
+                                                                          VerifyArgs A)
+{
+    using G            = XformGeom<LOGN>;
+    constexpr int N    = G::N;
+    constexpr int CTOP = LOGN - 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds32  = reinterpret_cast<uint32_t *>(smem);
+    double *plane    = reinterpret_cast<double *>(smem);
+    const int t      = threadIdx.x;
+    const size_t b   = blockIdx.x;
+    const int j      = A.j;
+    const uint32_t q = P.q[j], two_q = q << 1;
+    const size_t rec = (b * A.in_primes + (A.in_primes > 1 ? j : 0)) * N + 16 * t;
+
+    uint32_t x[16];
+    load16(x, A.c0 + rec);
+    if (A.c1)
+    {
+        uint32_t a[16], w[16], wp[16];
+        load16(a, A.c1 + rec);
+        load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            x[e] = csub(csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q) + x[e], q);
+    }
+    if (A.dec_ntt) store16(A.dec_ntt + b * N + 16 * t, x);
+    if (!A.pt && !A.values) return;
+
+    intt_tiles<LOGN>(x, T.intt_rw + (size_t)2 * N * j, q, lds32, t);
+    const uint32_t inv_n = P.inv_n[j], inv_n_sh = P.inv_n_sh[j];
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = csub(mul_shoup_lazy(x[e], inv_n, inv_n_sh, q), q);
+    if (A.pt)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) A.pt[b * N + (e << CTOP) + t] = x[e];
+    }
+    if (!A.values) return;
+
+    double re[16], im[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        // representative in (-q/2, q/2], then 1/scale (ckks_tests_common.c:74-83)
+        double dval = (x[e] > q / 2) ? -(double)(q - x[e]) : (double)x[e];
+        re[e]       = __ddiv_rn(dval, P.scale);
+        im[e]       = 0.0;
+    }
+    fft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
+    // values_decoded[i] = (flpt) Re res[index_map[i]]: this thread holds res[16t + e]; the slot
+    // that reads it is inv_map[16t + e] when that is < n/2
+    const uint4 *mp = reinterpret_cast<const uint4 *>(T.inv_map + 16 * t);
+    uint4 m0 = mp[0], m1 = mp[1];
+    uint32_t packed[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        uint32_t i = (packed[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+        if (i < (uint32_t)(N / 2)) A.values[b * (N / 2) + i] = (float)re[e];
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_vfy(const DevParams &P, const DevTables &T, const VerifyArgs &A, size_t B,
+                             hipStream_t st)
+{
+    using G      = XformGeom<LOGN>;
+    size_t shmem = (size_t)G::SLOTS * sizeof(double);
+    (void)hipFuncSetAttribute((const void *)k_decrypt_decode<LOGN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((k_decrypt_decode<LOGN>), dim3((unsigned)B), dim3(G::THREADS), shmem, st, P, T, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_decrypt_decode(const DevParams &P, const DevTables &T, const uint32_t *c0,
+                                 const uint32_t *c1, uint32_t in_primes, int j, uint32_t *dec_ntt,
+                                 uint32_t *pt, float *values, size_t B, hipStream_t st)
+{
+    if (B == 0) return hipSuccess;
+    VerifyArgs A{c0, c1, dec_ntt, pt, values, in_primes, j};
+    switch (P.logn)
+    {
+        case 10: return launch_vfy<10>(P, T, A, B, st);
+        case 11: return launch_vfy<11>(P, T, A, B, st);
+        case 12: return launch_vfy<12>(P, T, A, B, st);
+        case 13: return launch_vfy<13>(P, T, A, B, st);
+        case 14: return launch_vfy<14>(P, T, A, B, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 // reduce_set_e_small (ckks_common.c:259-265) for every prime: int8 error -> residues, natural order,
 // into a [count][np][n] slab (public-key generation feeds them to k_ntt_fuse).
 __global__ void k_reduce_small(DevParams P, const int8_t *e, uint32_t *out, int count)

@@ -56,6 +56,9 @@ hipError_t launch_encode_rns(const DevParams &, const DevTables &, const EncArgs
                              size_t B, hipStream_t);
 hipError_t launch_ntt_fuse(const DevParams &, const DevTables &, const EncArgs &, int mode, int j,
                            size_t B, hipStream_t);
+hipError_t launch_decrypt_decode(const DevParams &, const DevTables &, const uint32_t *c0,
+                                 const uint32_t *c1, uint32_t in_primes, int j, uint32_t *dec_ntt,
+                                 uint32_t *pt, float *values, size_t B, hipStream_t);
 hipError_t launch_reduce_small(const DevParams &, const int8_t *e, uint32_t *out, size_t count, hipStream_t);
 hipError_t launch_ntt_polys(const DevParams &, const DevTables &, int j, uint32_t *polys,
                             uint32_t *pairs, size_t count, hipStream_t);

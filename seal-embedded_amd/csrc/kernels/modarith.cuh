@@ -95,6 +95,18 @@ __device__ __forceinline__ void reduce_signed16(const int64_t (&m)[16], uint32_t
     }
 }
 
+// Gentleman-Sande butterfly of the inverse NTT, inputs/outputs in [0,2q):
+// (U, V) -> (U + V, (U - V) * w)   (intt.c:188-195)
+__device__ __forceinline__ void gs_butterfly(uint32_t &x, uint32_t &y, uint32_t w, uint32_t wp,
+                                             uint32_t neg_q, uint32_t two_q)
+{
+    uint32_t s = x + y;                 // [0,4q)
+    uint32_t d = x + two_q - y;         // (0,4q)
+    x          = min(s, s - two_q);     // [0,2q)
+    uint32_t h = __umulhi(d, wp);
+    y          = (uint32_t)((uint64_t)h * (uint64_t)neg_q + (uint64_t)(d * w));  // [0,2q)
+}
+
 // [0,4q) -> [0,q)
 __device__ __forceinline__ uint32_t canon4(uint32_t x, uint32_t q, uint32_t two_q)
 {

@@ -197,4 +197,122 @@ __device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Verification side (used by k_decrypt_decode): inverse NTT and forward FFT, same tiling.
+// ------------------------------------------------------------------------------------------
+
+// INTT pass: Gentleman-Sande stages for local bits [B_LO, B_HI), ascending (intt.c:144-222;
+// the reference merges the 1/n scaling into its last round -- the caller multiplies by n^-1
+// afterwards, which is the same exact residue).
+template <int LOGN, int C, int B_LO, int B_HI>
+__device__ __forceinline__ void intt_pass(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
+                                          uint32_t neg_q, uint32_t two_q, int t)
+{
+    constexpr int N = 1 << LOGN;
+    const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
+    static_for<B_LO, B_HI>([&](auto bc) {
+        constexpr int b      = decltype(bc)::value;
+        constexpr int h      = N >> (C + b + 1);
+        constexpr int groups = 1 << (3 - b);
+        static_for<0, groups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int idx   = h + ((thi << (3 - b)) | g);
+            const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
+            static_for<0, (1 << b)>([&](auto rc) {
+                constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
+                constexpr int e1 = e0 | (1 << b);
+                gs_butterfly(x[e0], x[e1], rw.x, rw.y, neg_q, two_q);
+            });
+        });
+    });
+}
+
+// Whole INTT (without the final 1/n): input tile layout 0, values < 2q; output tile layout
+// LOGN-4, values in [0,2q).
+template <int LOGN>
+__device__ __forceinline__ void intt_tiles(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
+                                           uint32_t q, uint32_t *lds, int t)
+{
+    using G              = XformGeom<LOGN>;
+    const uint32_t two_q = q << 1, neg_q = 0u - q;
+    intt_pass<LOGN, 0, 0, 4>(x, RW, neg_q, two_q, t);
+    redeal<0, 4>(x, lds, t);
+    intt_pass<LOGN, 4, 0, 4>(x, RW, neg_q, two_q, t);
+    if constexpr (LOGN <= 12)
+    {
+        constexpr int C2 = G::ifft_c(2);
+        redeal<4, C2>(x, lds, t);
+        intt_pass<LOGN, C2, 8 - C2, 4>(x, RW, neg_q, two_q, t);
+    }
+    else
+    {
+        redeal<4, 8>(x, lds, t);
+        intt_pass<LOGN, 8, 0, 4>(x, RW, neg_q, two_q, t);
+        constexpr int C3 = G::ifft_c(3);
+        redeal<8, C3>(x, lds, t);
+        intt_pass<LOGN, C3, 12 - C3, 4>(x, RW, neg_q, two_q, t);
+    }
+}
+
+// Forward FFT pass (fft.c:146-213): DIT stages for local bits [B_LO, B_HI), descending;
+// (u, v) -> (u + v*s, u - v*s) with s = conj(W[h + j]) = (W.re, -W.im), product in Annex-G order.
+template <int LOGN, int C, int B_LO, int B_HI>
+__device__ __forceinline__ void fft_pass(double (&re)[16], double (&im)[16],
+                                         const double *__restrict__ W, int t)
+{
+    constexpr int N = 1 << LOGN;
+    const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
+    static_for<0, B_HI - B_LO>([&](auto sc) {
+        constexpr int b      = B_HI - 1 - decltype(sc)::value;
+        constexpr int h      = N >> (C + b + 1);
+        constexpr int groups = 1 << (3 - b);
+        static_for<0, groups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int idx   = h + ((thi << (3 - b)) | g);
+            const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
+            const double c = w.x, d = -w.y;
+            static_for<0, (1 << b)>([&](auto rc) {
+                constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
+                constexpr int e1 = e0 | (1 << b);
+                double vr = __dsub_rn(__dmul_rn(re[e1], c), __dmul_rn(im[e1], d));
+                double vi = __dadd_rn(__dmul_rn(re[e1], d), __dmul_rn(im[e1], c));
+                re[e1]    = __dsub_rn(re[e0], vr);
+                im[e1]    = __dsub_rn(im[e0], vi);
+                re[e0]    = __dadd_rn(re[e0], vr);
+                im[e0]    = __dadd_rn(im[e0], vi);
+            });
+        });
+    });
+}
+
+// Whole forward FFT: input tile layout LOGN-4, output tile layout 0.
+template <int LOGN>
+__device__ __forceinline__ void fft_tiles(double (&re)[16], double (&im)[16],
+                                          const double *__restrict__ W, double *plane, int t)
+{
+    using G          = XformGeom<LOGN>;
+    constexpr int C0 = LOGN - 4;
+    fft_pass<LOGN, C0, 0, 4>(re, im, W, t);
+    constexpr int C1 = G::ntt_c(1);
+    redeal<C0, C1>(re, plane, t);
+    redeal<C0, C1>(im, plane, t);
+    fft_pass<LOGN, C1, 0, 4>(re, im, W, t);
+    if constexpr (LOGN <= 12)
+    {
+        redeal<C1, 0>(re, plane, t);
+        redeal<C1, 0>(im, plane, t);
+        fft_pass<LOGN, 0, 0, C1>(re, im, W, t);
+    }
+    else
+    {
+        constexpr int C2 = G::ntt_c(2);
+        redeal<C1, C2>(re, plane, t);
+        redeal<C1, C2>(im, plane, t);
+        fft_pass<LOGN, C2, 0, 4>(re, im, W, t);
+        redeal<C2, 0>(re, plane, t);
+        redeal<C2, 0>(im, plane, t);
+        fft_pass<LOGN, 0, 0, C2>(re, im, W, t);
+    }
+}
+
 }  // namespace seamd

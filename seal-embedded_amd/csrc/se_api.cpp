@@ -179,6 +179,33 @@ int se_amd_ntt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t c
     return SE_SUCCESS;
 }
 
+int se_amd_intt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t count, void *stream)
+{
+    if (!ctx || !d_polys || prime >= ctx->c.hp.nprimes) return SE_ERR_INVALD_ARGUMENT;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    // in place: natural-order result written back over the input polynomial
+    SEAMD_HIP(seamd::launch_decrypt_decode(ctx->c.dp, ctx->c.dt, d_polys, nullptr, 1, (int)prime,
+                                           nullptr, d_polys, nullptr, count, as_stream(stream)));
+    return SE_SUCCESS;
+}
+
+int se_amd_decrypt_decode_device(se_amd_ctx *ctx, const uint32_t *d_c0, const uint32_t *d_c1,
+                                 size_t B, size_t prime, uint32_t *d_dec_ntt, uint32_t *d_pt,
+                                 float *d_values, void *stream)
+{
+    if (!ctx || !d_c0 || !d_c1 || prime >= ctx->c.hp.nprimes) return SE_ERR_INVALD_ARGUMENT;
+    if (!ctx->c.have_sk)
+    {
+        seamd::set_last_error("decrypt needs the secret key (se_amd_set_secret_key)");
+        return SE_ERR_NO_KEY;
+    }
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    SEAMD_HIP(seamd::launch_decrypt_decode(ctx->c.dp, ctx->c.dt, d_c0, d_c1,
+                                           (uint32_t)ctx->c.hp.nprimes, (int)prime, d_dec_ntt, d_pt,
+                                           d_values, B, as_stream(stream)));
+    return SE_SUCCESS;
+}
+
 int se_amd_prng_blocks_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctrs,
                               uint8_t *d_out, size_t outlen, size_t count, void *stream)
 {

@@ -39,7 +39,7 @@ Context::~Context()
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
-    void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1,
+    void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
                     d_err,     d_ucodes, d_ctr,    d_rej};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -92,6 +92,21 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     for (size_t j = 0; j < nprimes; j++)
         SEAMD_HIP(hipEventCreateWithFlags(&ev_prime[j], hipEventDisableTiming));
+    {
+        std::vector<uint32_t> irw_all(2 * n * nprimes), irw;
+        for (size_t j = 0; j < nprimes; j++)
+        {
+            host_intt_root_pairs(hp, j, irw);
+            memcpy(irw_all.data() + 2 * n * j, irw.data(), 2 * n * sizeof(uint32_t));
+        }
+        SEAMD_HIP(hipMalloc((void **)&d_intt_rw, irw_all.size() * sizeof(uint32_t)));
+        SEAMD_HIP(hipMemcpy(d_intt_rw, irw_all.data(), irw_all.size() * sizeof(uint32_t),
+                            hipMemcpyHostToDevice));
+        SEAMD_HIP(hipMalloc((void **)&d_map, n * sizeof(uint16_t)));
+        SEAMD_HIP(hipMemcpy(d_map, index_map.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+        dt.intt_rw   = d_intt_rw;
+        dt.index_map = d_map;
+    }
     dt.inv_map = d_inv_map;
     dt.ifft_w  = d_ifft_w;
     dt.ntt_rw  = d_ntt_rw;

@@ -31,6 +31,8 @@ struct Context
     uint16_t *d_inv_map = nullptr;
     double *d_ifft_w    = nullptr;
     uint32_t *d_ntt_rw  = nullptr;
+    uint32_t *d_intt_rw = nullptr;
+    uint16_t *d_map     = nullptr;
     uint32_t *d_s_hat   = nullptr;
     uint32_t *d_pk0     = nullptr;
     uint32_t *d_pk1     = nullptr;

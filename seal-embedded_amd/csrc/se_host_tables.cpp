@@ -101,6 +101,13 @@ DevParams to_dev_params(const HostParams &hp)
         d.bound[j] = 0xFFFFFFFFu - (0xFFFFFFFFu % hp.q[j]) - 1u;
     }
     d.n_inv = hp.scale / (double)hp.n;
+    d.scale = hp.scale;
+    for (size_t j = 0; j < hp.nprimes; j++)
+    {
+        uint32_t inv  = host_inv_mod((uint32_t)(hp.n % hp.q[j]), hp.q[j]);
+        d.inv_n[j]    = inv;
+        d.inv_n_sh[j] = (uint32_t)(((uint64_t)inv << 32) / hp.q[j]);
+    }
     return d;
 }
 
@@ -153,6 +160,42 @@ void host_ntt_root_pairs(const HostParams &hp, size_t j, std::vector<uint32_t> &
         rw[2 * slot]     = (uint32_t)power;
         rw[2 * slot + 1] = (uint32_t)((power << 32) / q);  // Shoup companion floor(w 2^32 / q)
         power            = power * hp.psi[j] % q;
+    }
+}
+
+// a^-1 mod q for prime q (Fermat)
+uint32_t host_inv_mod(uint32_t a, uint32_t q)
+{
+    uint64_t r = 1, b = a % q, e = (uint64_t)q - 2;
+    while (e)
+    {
+        if (e & 1) r = r * b % q;
+        b = b * b % q;
+        e >>= 1;
+    }
+    return (uint32_t)r;
+}
+
+// intt.c:26-58 (one-shot form) / :160-177 (on-the-fly form): the root used by group g of the round
+// with h groups is psi^-bitrev(h + g); stored at index h + g like the forward table.
+void host_intt_root_pairs(const HostParams &hp, size_t j, std::vector<uint32_t> &rw)
+{
+    const size_t n         = hp.n;
+    const uint64_t q       = hp.q[j];
+    const uint64_t inv_psi = host_inv_mod(hp.psi[j], hp.q[j]);
+    std::vector<uint32_t> pw(n);
+    uint64_t power = 1;
+    for (size_t i = 0; i < n; i++)
+    {
+        pw[i] = (uint32_t)power;
+        power = power * inv_psi % q;
+    }
+    rw.assign(2 * n, 0);
+    for (size_t idx = 0; idx < n; idx++)
+    {
+        uint64_t w      = pw[bitrev(idx, hp.logn)];
+        rw[2 * idx]     = (uint32_t)w;
+        rw[2 * idx + 1] = (uint32_t)((w << 32) / q);
     }
 }
 

@@ -27,5 +27,7 @@ size_t bitrev(size_t x, size_t nbits);
 void host_index_map(const HostParams &hp, std::vector<uint16_t> &map, std::vector<uint16_t> &inv);
 void host_ifft_twiddles(const HostParams &hp, std::vector<double> &w);            // [n][2]
 void host_ntt_root_pairs(const HostParams &hp, size_t j, std::vector<uint32_t> &rw);  // [n][2]
+void host_intt_root_pairs(const HostParams &hp, size_t j, std::vector<uint32_t> &rw); // [n][2]
+uint32_t host_inv_mod(uint32_t a, uint32_t q);
 
 }  // namespace seamd

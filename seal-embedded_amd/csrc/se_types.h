@@ -20,6 +20,9 @@ struct DevParams
     uint32_t cr_lo[kMaxPrimes];    // floor(2^64/q) & 0xffffffff
     uint32_t bound[kMaxPrimes];    // uniform rejection bound (sample.c:46)
     double n_inv;                  // scale / n (ckks_common.c:183)
+    uint32_t inv_n[kMaxPrimes];    // n^-1 mod q            (intt.c:230-420 constants)
+    uint32_t inv_n_sh[kMaxPrimes]; // floor(inv_n * 2^32 / q)
+    double scale;                  // CKKS scale (decode divides by it)
 };
 
 // Device-resident read-only tables (pointers into one HBM slab owned by the context).
@@ -31,6 +34,8 @@ struct DevTables
     const uint32_t *s_hat;     // [np][n][2] (NTT(s), shoup)       sym
     const uint32_t *pk0;       // [np][n][2] (pk0, shoup)          asym
     const uint32_t *pk1;       // [np][n][2] (pk1, shoup)          asym
+    const uint32_t *intt_rw;   // [np][n][2] (psi^-bitrev(h+g), shoup) indexed h + g (intt.c:26-58)
+    const uint16_t *index_map; // [n] forward index map (decode slot pick)
 };
 
 enum Mode : int

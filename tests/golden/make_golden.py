@@ -168,6 +168,20 @@ def main():
                 small["sym_c0"], small["sym_c1"], small["sym_pte"] = r["c0"], r["c1"], r["pte"]
                 small["sym_c1_alias"] = r["c1_alias"]
 
+        # verification side: the reference's own decrypt / intt / decode on one of its ciphertexts
+        vv = V.pattern_values(4, n)                       # all 1.1 (fits every parameter set)
+        r = R.encrypt_sym(vv, SEED_A, SEED_B)
+        ver = {}
+        for j in range(nprimes):
+            dec = R.decrypt(r["c0"][j], r["c1"][j], r["ntt_s"][j], j)
+            assert (dec == r["c1_alias"][j]).all()
+            ptj = R.intt(dec, j)
+            val = R.decode(ptj, j)
+            assert np.abs(val - vv).max() < 0.1          # ckks_tests_common.c:132
+            ver[f"p{j}"] = {"pt_sha256": V.sha256_hex(ptj), "values_sha256": V.sha256_hex(val),
+                            "pt_ends": ends(ptj), "values_head": [float(x) for x in val[:4]]}
+        d["verify_pattern4"] = ver
+
         # G7 asymmetric end to end; pk from the reference's own gen_pk
         pk0, pk1 = Reference.gen_pk(n, nprimes, sk, SEED_PK, SEED_EP)
         RA = Reference(n, nprimes, asym=True)

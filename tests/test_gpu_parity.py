@@ -353,6 +353,54 @@ def test_gen_public_key_vs_reference_golden(env, golden, shape):
     assert (pk0 == o0).all() and (pk1 == o1).all()
 
 
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_intt_and_decrypt_decode_vs_oracle_and_golden(env, golden, shape):
+    """Verification side: batched ckks_decrypt + intt_inpl + ckks_decode on the
+    GPU, bit-exact against the oracle and the compiled reference's golden digests, plus the
+    reference's own acceptance criteria (exact pseudo-decrypt, decode within 0.1)."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    g = golden["digests"]["shapes"][f"{n}x{npr}"]["verify_pattern4"]
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    B = 5
+    vals = np.stack([V.pattern_values(4, n)] + [V.pattern_values(t, n) * 0.01 for t in (2, 5, 6, 8)])
+    ss = np.stack([np.frombuffer(SEED_A, dtype=np.uint8)] * B).copy()
+    sd = np.stack([np.frombuffer(SEED_B, dtype=np.uint8)] * B).copy()
+    ss[1:] = V.derive_seeds("vfy-a", B - 1)
+    sd[1:] = V.derive_seeds("vfy-b", B - 1)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    ntt_pte = torch.zeros_like(c0)
+    ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, ntt_pte)
+    for j in range(npr):
+        dec = torch.zeros((B, n), dtype=torch.int32, device=env["dev"])
+        pt = torch.zeros_like(dec)
+        out = torch.zeros((B, n // 2), dtype=torch.float32, device=env["dev"])
+        ctx.decrypt_decode(c0, c1, j, dec, pt, out)
+        torch.cuda.synchronize()
+        gd, gp, gv = host_u32(dec), host_u32(pt), out.cpu().numpy()
+        assert (gd == host_u32(ntt_pte)[:, j, :]).all()            # exact pseudo-decrypt
+        assert V.sha256_hex(gp[0]) == g[f"p{j}"]["pt_sha256"]
+        assert V.sha256_hex(gv[0]) == g[f"p{j}"]["values_sha256"]
+        for b in range(B):
+            ptj = o.intt(gd[b], j)
+            assert (gp[b] == ptj).all(), (j, b)
+            assert (gv[b].view(np.uint32) == o.decode(ptj, j).view(np.uint32)).all(), (j, b)
+            assert np.abs(gv[b] - vals[b]).max() < 0.1            # ckks_tests_common.c:132
+        # stand-alone INTT inverts the stand-alone NTT
+        rng = np.random.default_rng(n + j)
+        x = rng.integers(0, o.q[j], (3, n), dtype=np.uint64).astype(np.uint32)
+        t = dev_t(env, x.view(np.int32))
+        ctx.ntt(j, t)
+        ctx.intt(j, t)
+        torch.cuda.synchronize()
+        assert (host_u32(t) == x).all()
+
+
 def test_encode_only_config5(env):
     from oracle.pyoracle import Oracle
     torch = env["torch"]
@@ -444,6 +492,14 @@ def test_full_size_properties_config2(env):
         assert bool((lhs == ntt_pte[:, j, :].to(torch.int64)).all()), j
         assert int(c0[:, j, :].max()) < q and int(c0[:, j, :].min()) >= 0
         assert int(c1[:, j, :].max()) < q and int(c1[:, j, :].min()) >= 0
+    # (a') the same criterion plus decode-within-0.1 through the on-GPU verifier
+    # (se_amd_decrypt_decode_device), every ciphertext, prime 0
+    dec = torch.zeros((B, n), dtype=torch.int32, device=env["dev"])
+    dvals = torch.zeros((B, n // 2), dtype=torch.float32, device=env["dev"])
+    ctx.decrypt_decode(c0, c1, 0, dec, None, dvals)
+    torch.cuda.synchronize()
+    assert bool((dec == ntt_pte[:, 0, :]).all())
+    assert float((dvals - dv).abs().max()) < 0.1          # ckks_tests_common.c:132,228
     for b in (0, 1, 63, 64, B // 2 + 17, B - 1):
         r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
         assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b

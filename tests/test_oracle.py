@@ -160,6 +160,20 @@ def test_oracle_vs_golden(golden, shape):
         assert V.sha256_hex(r["ntt_pte"]) == g["c1_alias_sha256"]   # the alias quirk, SURVEY 0.5
         assert [ends(r["c0"][j]) for j in range(npr)] == g["c0_ends"]
 
+    # verification side (intt / decrypt / decode) against the reference's own helpers
+    vv = V.pattern_values(4, n)
+    r = o.encrypt_sym(vv, SEED_A, SEED_B, sk)
+    for j in range(npr):
+        gv = d["verify_pattern4"][f"p{j}"]
+        s_hat = o.ntt(o.expand_ternary(sk, j), j)
+        dec = o.decrypt(r["c0"][j], r["c1"][j], s_hat, j)
+        assert (dec == r["ntt_pte"][j]).all()
+        ptj = o.intt(dec, j)
+        assert V.sha256_hex(ptj) == gv["pt_sha256"]
+        val = o.decode(ptj, j)
+        assert V.sha256_hex(val) == gv["values_sha256"]
+        assert np.abs(val - vv).max() < 0.1
+
     g = d["asym_survey"]
     pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
     assert V.sha256_hex(pk0) == g["pk0_sha256"] and V.sha256_hex(pk1) == g["pk1_sha256"]
