@@ -90,7 +90,7 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    for (size_t j = 0; j < nprimes; j++)
+    for (size_t j = 0; j < (size_t)kMaxPrimes; j++)
         SEAMD_HIP(hipEventCreateWithFlags(&ev_prime[j], hipEventDisableTiming));
     {
         std::vector<uint32_t> irw_all(2 * n * nprimes), irw;
@@ -376,22 +376,50 @@ int Context::encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seed
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n;
 
-    // u first: its redraws decide where the CBD counters start (ckks_asym.c:188-201)
-    TernaryArgs ta{d_seeds, d_ucodes, d_ctr, n, (uint32_t)B};
-    stage_begin(2, st);
-    SEAMD_HIP(launch_sample_ternary(ta, st));
-    stage_end(st);
-
-    // e0 (blocks 0..n/16-1) then e1 (blocks n/16..2n/16-1), contiguous per ciphertext
-    CbdArgs ca{d_seeds, d_ctr, d_err, 2 * (n / 16), (uint32_t)B};
-    stage_begin(0, st);
-    SEAMD_HIP(launch_sample_cbd(ca, st));
-    stage_end(st);
-
-    EncArgs ea{d_values, d_err, d_ucodes, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
-    stage_begin(3, st);
-    SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeAsym, B, st));
-    stage_end(st);
+    // Per chunk: u first (its redraws decide where the CBD counters start, ckks_asym.c:188-201),
+    // then e0 (blocks 0..n/16-1) and e1 (blocks n/16..2n/16-1) contiguous per ciphertext, then the
+    // fused kernel.  The loop can cut the batch into chunks and run the samplers of chunk i+1 on
+    // the auxiliary stream beside the fused kernel of chunk i; measured at n=4096, B=65536 this is
+    // SLOWER (14.1 vs 12.2 ms per step): the ternary sampler is a per-ciphertext chain whose
+    // duration does not shrink with the chunk, and the fused kernel slows down when it shares the
+    // VALU.  One chunk is therefore the default.
+    const size_t nchunks = 1;
+    const size_t np      = hp.nprimes;
+    hipStream_t ax       = nchunks > 1 ? aux_stream : st;
+    if (nchunks > 1)
+    {
+        SEAMD_HIP(hipEventRecord(ev_fork, st));
+        SEAMD_HIP(hipStreamWaitEvent(ax, ev_fork, 0));
+    }
+    for (size_t c = 0; c < nchunks; c++)
+    {
+        const size_t lo = B * c / nchunks, hi = B * (c + 1) / nchunks, cb = hi - lo;
+        if (cb == 0) continue;
+        TernaryArgs ta{d_seeds + lo * 64, d_ucodes + lo * n, d_ctr + lo, n, (uint32_t)cb};
+        stage_begin(2, ax);
+        SEAMD_HIP(launch_sample_ternary(ta, ax));
+        stage_end(ax);
+        CbdArgs ca{d_seeds + lo * 64, d_ctr + lo, d_err + lo * 2 * n, 2 * (n / 16), (uint32_t)cb};
+        stage_begin(0, ax);
+        SEAMD_HIP(launch_sample_cbd(ca, ax));
+        stage_end(ax);
+        if (nchunks > 1)
+        {
+            SEAMD_HIP(hipEventRecord(ev_prime[c], ax));
+            SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[c], 0));
+        }
+        EncArgs ea{d_values + lo * (n / 2),
+                   d_err + lo * 2 * n,
+                   d_ucodes + lo * n,
+                   d_c0 + lo * np * n,
+                   d_c1 + lo * np * n,
+                   d_ntt_pte ? d_ntt_pte + lo * np * n : nullptr,
+                   d_pte ? d_pte + lo * n : nullptr,
+                   d_status ? d_status + lo : nullptr};
+        stage_begin(3, st);
+        SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeAsym, cb, st));
+        stage_end(st);
+    }
     return 0;
 }
 
