@@ -164,6 +164,15 @@ int se_amd_encrypt_sym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
                               const uint8_t *d_share_seeds, const uint8_t *d_seeds, uint32_t *d_c0,
                               uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte,
                               uint8_t *d_status, void *stream);
+/* Seed-compressed symmetric ciphertext (the reference has only a stub, seal_embedded.c:184-194):
+ * c1 = a is the expansion of the 64-byte shareable seed from counter 0 (sample.c:39-57 over the
+ * prime chain), so only (share_seed, c0) need to travel; se_amd_expand_c1_device regenerates c1 on
+ * the receiving side, bit-identical to what se_amd_encrypt_sym_device would have returned. */
+int se_amd_encrypt_sym_seeded_device(se_amd_ctx *ctx, const float *d_values, size_t B,
+                                     const uint8_t *d_share_seeds, const uint8_t *d_seeds,
+                                     uint32_t *d_c0, uint8_t *d_status, void *stream);
+int se_amd_expand_c1_device(se_amd_ctx *ctx, const uint8_t *d_share_seeds, size_t B, uint32_t *d_c1,
+                            void *stream);
 int se_amd_encrypt_asym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
                                const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
                                uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,

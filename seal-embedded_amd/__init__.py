@@ -43,7 +43,8 @@ EXPORTED_SYMBOLS = (
     "se_cleanup", "se_encrypt_batch",
     "se_amd_create", "se_amd_destroy", "se_amd_degree", "se_amd_nprimes", "se_amd_scale",
     "se_amd_moduli", "se_amd_index_map", "se_amd_set_secret_key", "se_amd_set_public_key",
-    "se_amd_load_keys_from_dir", "se_amd_gen_public_key", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device",
+    "se_amd_load_keys_from_dir", "se_amd_gen_public_key", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device", "se_amd_encrypt_sym_seeded_device",
+    "se_amd_expand_c1_device",
     "se_amd_encode_ntt_device", "se_amd_encrypt_sym_host", "se_amd_encrypt_asym_host",
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_intt_device", "se_amd_decrypt_decode_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
@@ -84,6 +85,8 @@ def lib():
     L.se_amd_gen_public_key.argtypes = [vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_sym_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_asym_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.se_amd_encrypt_sym_seeded_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
+    L.se_amd_expand_c1_device.argtypes = [vp, vp, sz, vp, vp]
     L.se_amd_encode_ntt_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.se_amd_encrypt_sym_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_asym_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp]
@@ -210,6 +213,16 @@ class Context:
                                                 _ptr(seeds), _ptr(c0), _ptr(c1), _ptr(ntt_pte),
                                                 _ptr(pte), _ptr(status), _stream_ptr()),
                "se_amd_encrypt_sym_device")
+
+    def encrypt_sym_seeded(self, values, share_seeds, seeds, c0, status=None):
+        _check(self.L.se_amd_encrypt_sym_seeded_device(self.h, _ptr(values), values.shape[0],
+                                                       _ptr(share_seeds), _ptr(seeds), _ptr(c0),
+                                                       _ptr(status), _stream_ptr()),
+               "se_amd_encrypt_sym_seeded_device")
+
+    def expand_c1(self, share_seeds, c1):
+        _check(self.L.se_amd_expand_c1_device(self.h, _ptr(share_seeds), share_seeds.shape[0],
+                                              _ptr(c1), _stream_ptr()), "se_amd_expand_c1_device")
 
     def encrypt_asym(self, values, seeds, c0, c1, ntt_pte=None, pte=None, status=None):
         B = values.shape[0]

@@ -142,6 +142,36 @@ int se_amd_encrypt_sym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
                               d_status, as_stream(stream));
 }
 
+// Seed-compressed symmetric ciphertext (the reference only has a stub for it,
+// seal_embedded.c:184-194): c1 = a is a deterministic expansion of the 64-byte shareable seed
+// from counter 0, so a sender ships (share_seed, c0) -- half the bytes -- and the receiver
+// re-expands a with se_amd_expand_c1_device (= sample_poly_uniform over the prime chain).
+int se_amd_encrypt_sym_seeded_device(se_amd_ctx *ctx, const float *d_values, size_t B,
+                                     const uint8_t *d_share_seeds, const uint8_t *d_seeds,
+                                     uint32_t *d_c0, uint8_t *d_status, void *stream)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    Context &c = ctx->c;
+    if (B > c.a_cap)
+    {
+        SEAMD_HIP(hipSetDevice(c.device));
+        SEAMD_HIP(hipDeviceSynchronize());
+        if (c.d_a) (void)hipFree(c.d_a);
+        c.d_a   = nullptr;
+        c.a_cap = 0;
+        SEAMD_HIP(hipMalloc((void **)&c.d_a, B * c.hp.nprimes * c.hp.n * sizeof(uint32_t)));
+        c.a_cap = B;
+    }
+    return c.encrypt_sym(d_values, B, d_share_seeds, d_seeds, d_c0, c.d_a, nullptr, nullptr, d_status,
+                         as_stream(stream));
+}
+
+int se_amd_expand_c1_device(se_amd_ctx *ctx, const uint8_t *d_share_seeds, size_t B, uint32_t *d_c1,
+                            void *stream)
+{
+    return se_amd_sample_uniform_device(ctx, d_share_seeds, nullptr, B, d_c1, nullptr, stream);
+}
+
 int se_amd_encrypt_asym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
                                const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
                                uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, void *stream)

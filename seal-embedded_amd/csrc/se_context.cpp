@@ -40,7 +40,7 @@ Context::~Context()
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
-                    d_err,     d_ucodes, d_ctr,    d_rej};
+                    d_err,     d_ucodes, d_ctr,    d_rej, d_a};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }

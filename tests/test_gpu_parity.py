@@ -401,6 +401,27 @@ def test_intt_and_decrypt_decode_vs_oracle_and_golden(env, golden, shape):
         assert (host_u32(t) == x).all()
 
 
+def test_seed_compressed_symmetric_ciphertext(env):
+    """(share_seed, c0) travels; the receiver re-expands c1 = a from the seed."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 65
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n, first=500)
+    ss, sd = V.bench_seeds(B, first=500)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    ctx.encrypt_sym_seeded(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0)
+    c1 = torch.zeros_like(c0)
+    env["pkg"].Context(n, npr).expand_c1(dev_t(env, ss), c1)     # a different ("receiver") context
+    torch.cuda.synchronize()
+    for b in (0, 1, 63, 64):
+        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all()
+
+
 def test_encode_only_config5(env):
     from oracle.pyoracle import Oracle
     torch = env["torch"]
