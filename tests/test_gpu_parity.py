@@ -401,6 +401,36 @@ def test_intt_and_decrypt_decode_vs_oracle_and_golden(env, golden, shape):
         assert (host_u32(t) == x).all()
 
 
+@pytest.mark.parametrize("shape", [(16384, 13), (8192, 1), (4096, 1), (4096, 2), (16384, 1)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+def test_other_prime_counts_including_maximum(env, shape):
+    """Every (degree, nprimes) the reference accepts is a prefix of its prime chain
+    (parameters.c:176-230); the largest is n=16384 with all 13 primes."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    B = 3
+    o = Oracle(n, npr)
+    sk = V.secret_key(n, seed=21)
+    ctx = env["pkg"].Context(n, npr)
+    assert ctx.moduli() == o.q and ctx.scale() == o.scale
+    assert (ctx.index_map() == o.map).all()
+    ctx.set_secret_key(sk)
+    vals = V.bench_values(B, n, first=90) * np.float32(0.05)
+    ss, sd = V.bench_seeds(B, first=90)
+    r = ctx.encrypt_sym_host(vals, ss, sd, want_extra=True)
+    assert r["failed"] == 0
+    pk0, pk1 = ctx.gen_public_key(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    ra = ctx.encrypt_asym_host(vals, sd)
+    for b in range(B):
+        e = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (r["c0"][b] == e["c0"]).all() and (r["c1"][b] == e["c1"]).all()
+        assert (r["pte"][b] == e["pte"]).all()
+        ea = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+        assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all()
+
+
 def test_seed_compressed_symmetric_ciphertext(env):
     """(share_seed, c0) travels; the receiver re-expands c1 = a from the seed."""
     from oracle.pyoracle import Oracle
