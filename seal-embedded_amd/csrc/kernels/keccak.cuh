@@ -135,6 +135,20 @@ __device__ __forceinline__ void keccak_f1600(KeccakState &s)
     for (int r = 0; r < 24; r++) keccak_round(s, kKeccakRC[r][0], kKeccakRC[r][1]);
 }
 
+// Same permutation with the first and the last round peeled out of the loop.  For a freshly
+// absorbed PRNG message most lanes of the input state are compile-time constants (lanes 10..15 and
+// 17..24 are zero, lane 9 = 0x1F, lane 16 = 1<<63), so the peeled round 0 constant-folds (~40 of
+// its 190 ops disappear); and when the caller only consumes part of the output (the first word
+// for a redraw, 96 bytes for a CBD / ternary block) dead-code elimination prunes the peeled last
+// round (~150 resp. ~70 ops).  Use right after prng_absorb().
+__device__ __forceinline__ void keccak_f1600_fresh(KeccakState &s)
+{
+    keccak_round(s, kKeccakRC[0][0], kKeccakRC[0][1]);
+#pragma unroll 2
+    for (int r = 1; r < 23; r++) keccak_round(s, kKeccakRC[r][0], kKeccakRC[r][1]);
+    keccak_round(s, kKeccakRC[23][0], kKeccakRC[23][1]);
+}
+
 // State after absorbing the 72-byte PRNG message seed[64] || le64(ctr) with SHAKE256 padding:
 // lanes 0..7 = seed, lane 8 = counter, lane 9 = 0x1F, lane 16 = 0x80 << 56 (byte 135).
 __device__ __forceinline__ void prng_absorb(KeccakState &s, const uint32_t (&seed)[16], uint64_t ctr)

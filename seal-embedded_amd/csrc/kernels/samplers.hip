@@ -164,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
             const uint32_t thi = (uint32_t)__shfl((int)(uint32_t)(ctr >> 32), (int)target);
             KeccakState cs;
             prng_absorb(cs, tseed, ((((uint64_t)thi) << 32) | tlo) + d);
-            keccak_f1600(cs);
+            keccak_f1600_fresh(cs);  // only cs.lo[0] is consumed
             const uint32_t cand = cs.lo[0];
 
             const uint32_t dmax = (63u / R) + 1u;  // most candidates any lane received
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_sample_cbd(CbdArgs A)
     uint64_t ctr = (A.ctr_base ? A.ctr_base[b] : 0) + k;
     KeccakState st;
     prng_absorb(st, seed, ctr);
-    keccak_f1600(st);
+    keccak_f1600_fresh(st);  // only 96 of the 200 state bytes are consumed
     uint32_t w[24];
 #pragma unroll
     for (int i = 0; i < 12; i++)
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_sample_ternary(TernaryArgs A)
     {
         KeccakState st;
         prng_absorb(st, seed, ctr);
-        keccak_f1600(st);
+        keccak_f1600_fresh(st);  // a block uses 96 bytes, a redraw 1 byte
         if (!done)
         {
             ctr++;
