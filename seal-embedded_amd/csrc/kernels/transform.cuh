@@ -72,10 +72,14 @@ __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
 {
 #pragma unroll
     for (int e = 0; e < 16; e++) lds[lds_slot(tile_index<C_FROM>(t, e))] = v[e];
+#ifndef SEAMD_ABL_NO_BARRIERS
     __syncthreads();
+#endif
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = lds[lds_slot(tile_index<C_TO>(t, e))];
+#ifndef SEAMD_ABL_NO_BARRIERS
     __syncthreads();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -96,7 +100,11 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             const int idx   = h + ((thi << (3 - b)) | g);
+#ifdef SEAMD_ABL_NO_ROOT_LOADS
+            const double2 w = make_double2(1.0 + idx, 0.5);
+#else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
+#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
@@ -158,7 +166,11 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             const int idx   = h + ((thi << (3 - b)) | g);
+#ifdef SEAMD_ABL_NO_ROOT_LOADS
+            const uint2 rw  = make_uint2(12345u + idx, 54321u);
+#else
             const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
+#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
