@@ -263,10 +263,11 @@ int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
 /* Pre-allocate the internal scratch for batches of up to B plaintexts (keeps hipMalloc out of
  * the first timed call). */
 int se_amd_reserve(se_amd_ctx *ctx, size_t B);
-/* timing ablations of the uniform sampler (tools/ablate.py); outputs are WRONG when non-zero. */
+/* timing ablations of the uniform sampler (tools/ablate.py): bits 1, 2, 4 make outputs WRONG;
+ * bit 8 only disables the helper waves small batches get for the redraw phase (results unchanged). */
 int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags);
 /* pipeline shape of the symmetric path (A/B experiments): overlap = use the auxiliary stream,
- * split = per-prime software pipeline (default 1, 1). */
+ * split = 0 fused kernel, 1 per-prime software pipeline, 2 choose per call (default 1, 2). */
 int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split);
 const char *se_amd_last_error(void);
 const char *se_amd_version(void);

@@ -30,8 +30,9 @@ struct UniformArgs
     uint32_t B;
     uint32_t prime_lo, prime_hi;
     uint32_t out_primes;
+    uint32_t master_waves; // waves of a workgroup that own ciphertexts (the rest are redraw helpers)
     uint32_t debug_flags;  // ablation (timing experiments only): 1 = no bulk stores, 2 = no phase 2,
-                           // 4 = no reject bookkeeping
+                           // 4 = no reject bookkeeping; 8 = no helper waves (results stay correct)
 };
 struct CbdArgs
 {

@@ -66,16 +66,34 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
     // per-wave rank -> lane table of the balanced redraw phase
     extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];
     const int lane      = threadIdx.x & 63;
-    uint8_t *rank2lane  = pin_lds + (threadIdx.x >> 6) * 64;
+    const int wave      = threadIdx.x >> 6;
+    uint8_t *rank2lane  = pin_lds + wave * 64;
 
-    const size_t bq   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = bq < A.B;          // lanes past the batch stay alive as redraw helpers
+    // Waves [0, master_waves) of the workgroup own one ciphertext per lane; any further waves are
+    // helpers that only take part in the redraw phase (small batches leave SIMDs empty otherwise).
+    const uint32_t mthreads = A.master_waves * 64;
+    const bool master = threadIdx.x < mthreads;
+    const size_t bq   = (size_t)blockIdx.x * mthreads + threadIdx.x;
+    const bool active = master && bq < A.B;   // lanes past the batch stay alive as redraw helpers
     const size_t b    = active ? bq : (size_t)A.B - 1;
+    const bool wg_pool = blockDim.x > mthreads;   // helper waves present: pool the whole workgroup
+
+    // workgroup-pool scratch (only used when wg_pool): carved from the reserved LDS
+    uint32_t *lds_seed  = reinterpret_cast<uint32_t *>(pin_lds + 1024);            // [mthreads][16]
+    uint64_t *lds_ctr   = reinterpret_cast<uint64_t *>(lds_seed + (size_t)mthreads * 16);
+    uint32_t *lds_cand  = reinterpret_cast<uint32_t *>(lds_ctr + mthreads);          // [blockDim]
+    uint16_t *lds_table = reinterpret_cast<uint16_t *>(lds_cand + blockDim.x);       // [mthreads]
+    uint32_t *lds_cnt   = reinterpret_cast<uint32_t *>(lds_table + mthreads);        // [16]
 
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
     uint64_t ctr     = A.ctr_in ? A.ctr_in[b] : 0;
     uint32_t *mylist = A.rej_list + b * A.rej_cap;
+    if (wg_pool && master)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++) lds_seed[threadIdx.x * 16 + i] = seed[i];
+    }
 
     for (uint32_t j = A.prime_lo; j < A.prime_hi; j++)
     {
@@ -144,7 +162,79 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
         uint32_t need    = (A.debug_flags & 2) ? 0u : nrej;
         uint32_t k       = 0;  // rejected coefficients resolved so far
         uint32_t scanpos = 0;  // list-overflow path: next index to scan for a marker
-        for (;;)
+
+        // one accepted candidate x for this lane's k-th rejected coefficient
+        auto place = [&](uint32_t x) {
+            uint32_t pos;
+            if (k < A.rej_cap)
+            {
+                pos = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+                // list overflow: rejected positions are exactly the marker words
+                pos = scanpos;
+                while (__hip_atomic_load(mypoly + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                       kRejMarker)
+                    pos++;
+            }
+            scanpos     = pos + 1;
+            mypoly[pos] = barrett32(x, q, crh);
+            k++;
+            need--;
+        };
+
+        // Workgroup pool (helper waves present): same dealing scheme as below, but over all
+        // 64*(masters+helpers) lanes of the workgroup, with seeds / counters / candidates passed
+        // through LDS and block barriers.
+        while (wg_pool)
+        {
+            const uint64_t wmask = __ballot(need > 0);
+            if (lane == 0) lds_cnt[wave] = (uint32_t)__popcll(wmask);
+            if (master) lds_ctr[threadIdx.x] = ctr;
+            __syncthreads();
+            uint32_t R = 0, base = 0;
+            const uint32_t nwaves = blockDim.x >> 6;
+            for (uint32_t w = 0; w < nwaves; w++)
+            {
+                uint32_t c = lds_cnt[w];
+                if (w < (uint32_t)wave) base += c;
+                R += c;
+            }
+            if (R == 0) break;  // uniform over the workgroup
+            const uint32_t grank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+            if (need > 0) lds_table[grank] = (uint16_t)threadIdx.x;
+            __syncthreads();
+            const uint32_t d      = threadIdx.x / R;
+            const uint32_t target = lds_table[threadIdx.x - d * R];
+            uint32_t tseed[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                uint4 v = *reinterpret_cast<const uint4 *>(lds_seed + target * 16 + 4 * i);
+                tseed[4 * i] = v.x, tseed[4 * i + 1] = v.y, tseed[4 * i + 2] = v.z, tseed[4 * i + 3] = v.w;
+            }
+            KeccakState cs;
+            prng_absorb(cs, tseed, lds_ctr[target] + d);
+            keccak_f1600_fresh(cs);
+            lds_cand[threadIdx.x] = cs.lo[0];
+            __syncthreads();
+            const uint32_t dmax = (blockDim.x - 1u) / R + 1u;
+            for (uint32_t dd = 0; dd < dmax; dd++)
+            {
+                const uint32_t src = grank + dd * R;
+                if (need > 0 && src < blockDim.x)
+                {
+                    const uint32_t x = lds_cand[src];
+                    ctr++;
+                    if (x < bound) place(x);
+                }
+            }
+            __syncthreads();
+        }
+
+        for (; !wg_pool;)
         {
             const uint64_t mask = __ballot(need > 0);
             if (mask == 0) break;
@@ -175,26 +265,7 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
                 if (need > 0 && src < 64u)
                 {
                     ctr++;
-                    if (x < bound)
-                    {
-                        uint32_t pos;
-                        if (k < A.rej_cap)
-                        {
-                            pos = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        else
-                        {
-                            // list overflow: rejected positions are exactly the marker words
-                            pos = scanpos;
-                            while (__hip_atomic_load(mypoly + pos, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT) != kRejMarker)
-                                pos++;
-                        }
-                        scanpos     = pos + 1;
-                        mypoly[pos] = barrett32(x, q, crh);
-                        k++;
-                        need--;
-                    }
+                    if (x < bound) place(x);
                 }
             }
         }
@@ -373,24 +444,30 @@ __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const 
 // launch workgroups of w waves (w = 1, 2, 3, 4, 8, 12, 16) and reserve > 80 KiB of dynamic LDS per
 // workgroup, which admits exactly one workgroup per CU: every CU gets the same number of waves
 // and the hardware deals a workgroup's waves round-robin over its 4 SIMDs.
-static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &lds_bytes)
+static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &lds_bytes,
+                           unsigned *master_waves = nullptr, bool allow_helpers = false)
 {
     const size_t waves = (B + 63) / 64;
     size_t w           = (waves + 255) / 256;   // waves per CU if spread over 256 CUs
     if (w < 1) w = 1;
     if (w > 4) w = ((w + 3) / 4) * 4;           // beyond one per SIMD: whole multiples of 4
     if (w > 16) w = 16;
-    threads   = (unsigned)(w * 64);
-    grid      = (unsigned)((B + threads - 1) / threads);
+    size_t helpers = 0;
+    if (allow_helpers && w < 4) helpers = 8 - w;  // small batch: fill the CU to 2 waves per SIMD
+    threads   = (unsigned)((w + helpers) * 64);   // with helper waves for the redraw phase
+    grid      = (unsigned)((B + w * 64 - 1) / (w * 64));
     lds_bytes = 84 * 1024;
+    if (master_waves) *master_waves = (unsigned)w;
 }
 
-hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A, hipStream_t st)
+hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipStream_t st)
 {
-    if (A.B == 0) return hipSuccess;
-    unsigned threads, grid_x;
+    if (A0.B == 0) return hipSuccess;
+    unsigned threads, grid_x, mw;
     size_t lds;
-    chain_geometry(A.B, threads, grid_x, lds);
+    chain_geometry(A0.B, threads, grid_x, lds, &mw, !(A0.debug_flags & 8));
+    UniformArgs A   = A0;
+    A.master_waves  = mw;
     dim3 grid(grid_x), block(threads);
 #define SEAMD_LAUNCH_UNIFORM(L)                                                                  \
     (void)hipFuncSetAttribute((const void *)k_sample_uniform<L>,                                 \

@@ -68,7 +68,7 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipSetDevice(device));
     dp = to_dev_params(hp);
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
-    split   = n >= 8192;  // >= 3x the expected rejections per polynomial
+    // rej_cap >= 3x the expected rejections per polynomial
 
     std::vector<uint16_t> inv;
     host_index_map(hp, index_map, inv);
@@ -221,7 +221,7 @@ int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, co
     EncArgs ea{nullptr, nullptr, nullptr, d_p0, d_p1, nullptr, nullptr, nullptr};
     for (uint32_t j = 0; j < np; j++)
     {
-        UniformArgs ua{d_seeds + 64, nullptr, nullptr, d_p1, d_rej, rej_cap, 1, j, j + 1, np, 0};
+        UniformArgs ua{d_seeds + 64, nullptr, nullptr, d_p1, d_rej, rej_cap, 1, j, j + 1, np, 0, 0};
         SEAMD_HIP(launch_sample_uniform(dp, ua, nullptr));
         SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, 1, nullptr));
     }
@@ -286,6 +286,8 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
     EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
 
+    const size_t chain_waves_per_cu = ((B + 63) / 64 + 255) / 256;
+    const bool split = split_mode == 1 || (split_mode == 2 && (hp.n >= 8192 || chain_waves_per_cu < 4));
     if (!split)
     {
         // Simple chain: [cbd on the aux stream || uniform] -> fused encode+encrypt.
@@ -299,7 +301,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
         SEAMD_HIP(launch_sample_cbd(ca, cbd_stream));
         stage_end(cbd_stream);
         if (overlap) SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
-        UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np,
+        UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np, 0,
                        debug_flags};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
@@ -333,7 +335,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     {
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
-                       j,             j + 1,               np,    debug_flags};
+                       j,             j + 1,               np,    0,           debug_flags};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
         stage_end(st);

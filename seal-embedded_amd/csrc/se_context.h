@@ -55,9 +55,11 @@ struct Context
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_prime[kMaxPrimes] = {};
     bool overlap = true;   // run independent kernels on the auxiliary stream
-    bool split   = false;  // symmetric path as encode_rns + per-prime (uniform_j || ntt_fuse_{j-1});
-                           // measured equal to the fused form at n=4096 (the chip is VALU-bound
-                           // either way); default on for n >= 8192 where the fused kernel spills
+    int split_mode = 2;    // symmetric path: 0 = fused kernel, 1 = per-prime software pipeline
+                           // (encode_rns + uniform_j || ntt_fuse_{j-1}), 2 = choose per call: the split
+                           // form wins whenever the uniform sampler's chains leave SIMDs empty (fewer
+                           // than 4 chain waves per CU) or the fused kernel spills (n >= 8192);
+                           // at n = 4096, B = 65536 both measure the same and fused moves less data
 
     // profiling
     bool profiling = false;

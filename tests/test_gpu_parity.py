@@ -69,20 +69,30 @@ def test_sample_uniform_vs_oracle(env, shape):
     torch = env["torch"]
     n, npr = shape
     B = 70  # crosses a wave boundary (64) and leaves a ragged tail
-    ctx = env["pkg"].Context(n, npr)
     o = Oracle(n, npr)
     seeds = seeds_np(B, f"uni-{n}")
-    out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
-    ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
-    ctx.sample_uniform(dev_t(env, seeds), out, ctr_out=ctr_out)
-    torch.cuda.synchronize()
-    got, gctr = host_u32(out), ctr_out.cpu().numpy()
+    exp, ectr = [], []
     for b in range(B):
-        ctr = 0
+        ctr, row = 0, []
         for j in range(npr):
             a, ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
-            assert (got[b, j] == a).all(), (b, j)
-        assert int(gctr[b]) == ctr
+            row.append(a)
+        exp.append(row)
+        ectr.append(ctr)
+    # flags 0: helper waves pool the redraw phase over the workgroup (the small-batch shape);
+    # flags 8: wave-local redraw phase (the shape a full 65 536 batch runs)
+    for flags in (0, 8):
+        ctx = env["pkg"].Context(n, npr)
+        ctx.set_debug_flags(flags)
+        out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+        ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+        ctx.sample_uniform(dev_t(env, seeds), out, ctr_out=ctr_out)
+        torch.cuda.synchronize()
+        got, gctr = host_u32(out), ctr_out.cpu().numpy()
+        for b in range(B):
+            for j in range(npr):
+                assert (got[b, j] == exp[b][j]).all(), (flags, b, j)
+            assert int(gctr[b]) == ectr[b]
 
 
 def test_sample_uniform_golden_and_ctr_in(env, golden):
@@ -122,12 +132,14 @@ def test_sample_uniform_reject_list_overflow_path(env):
         for j in range(npr):
             exp[b, j], ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
     for cap in (0, 1, 7, 64):
-        ctx = env["pkg"].Context(n, npr)
-        ctx.set_reject_list_capacity(cap)
-        out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
-        ctx.sample_uniform(dev_t(env, seeds), out)
-        torch.cuda.synchronize()
-        assert (host_u32(out) == exp).all(), cap
+        for flags in (0, 8):          # with and without the small-batch helper waves
+            ctx = env["pkg"].Context(n, npr)
+            ctx.set_reject_list_capacity(cap)
+            ctx.set_debug_flags(flags)
+            out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+            ctx.sample_uniform(dev_t(env, seeds), out)
+            torch.cuda.synchronize()
+            assert (host_u32(out) == exp).all(), (cap, flags)
 
 
 @pytest.mark.parametrize("n", [1024, 2048, 4096, 16384])
@@ -327,6 +339,7 @@ def test_all_pipeline_shapes_agree(env, shape):
     for overlap in (0, 1):
         for split in (0, 1):
             ctx.set_pipeline(overlap, split)
+            ctx.set_debug_flags(8 if (overlap + split) % 2 else 0)   # helper waves on / off
             c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
             c1 = torch.zeros_like(c0)
             ntt_pte = torch.zeros_like(c0)

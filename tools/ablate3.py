@@ -15,18 +15,18 @@ def timed(f, reps=3):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-for (n, npr, B) in ((16384, 6, 32768), (8192, 6, 32768)):
+for (n, npr, B) in ((16384, 6, 32768), (4096, 3, 16384), (4096, 3, 4096)):
     ctx = pkg.Context(n, npr); ctx.reserve(B); ctx.set_secret_key(V.secret_key(n))
     vals = torch.from_numpy(V.bench_values(2048, n)).to(dev).repeat(B // 2048, 1).contiguous()
     ss_np, sd_np = V.bench_seeds(B)
     ss, sd = torch.from_numpy(ss_np).to(dev), torch.from_numpy(sd_np).to(dev)
     c0 = torch.empty((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.empty_like(c0)
-    for ov, sp in ((1, 0), (0, 1), (1, 1)):
-        ctx.set_pipeline(ov, sp)
+    for ov, sp, fl in ((1, 1, 8), (1, 1, 0), (1, 0, 0)):
+        ctx.set_pipeline(ov, sp); ctx.set_debug_flags(fl)
         t = timed(lambda: ctx.encrypt_sym(vals, ss, sd, c0, c1))
         ctx.set_profiling(True); ctx.stage_ms(True)
         for _ in range(2): ctx.encrypt_sym(vals, ss, sd, c0, c1)
         torch.cuda.synchronize(); st = {k: round(v[0] / 2, 2) for k, v in ctx.stage_ms(True).items() if v[1]}
         ctx.set_profiling(False)
-        print(f"n={n} np={npr} B={B} overlap={ov} split={sp}: {t:.2f} ms  ({B/t/1e3:.1f}k ct/s)  {st}", flush=True)
+        print(f"n={n} np={npr} B={B} overlap={ov} split={sp} helpers={0 if fl else 1}: {t:.2f} ms  ({B/t:.1f}k ct/s)  {st}", flush=True)
     ctx.close(); del c0, c1, vals
