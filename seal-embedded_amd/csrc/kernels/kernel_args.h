@@ -30,6 +30,8 @@ struct UniformArgs
     uint32_t B;
     uint32_t prime_lo, prime_hi;
     uint32_t out_primes;
+    uint32_t *spec;        // [B][spec_cap] scratch: candidates precomputed by helper waves
+    uint32_t spec_cap;
     uint32_t master_waves; // waves of a workgroup that own ciphertexts (the rest are redraw helpers)
     uint32_t debug_flags;  // ablation (timing experiments only): 1 = no bulk stores, 2 = no phase 2,
                            // 4 = no reject bookkeeping; 8 = no helper waves (results stay correct)

@@ -101,11 +101,42 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
         uint32_t *mypoly = A.out + (b * A.out_primes + j) * (size_t)N;
 
         uint32_t nrej = 0;
+        const uint64_t bulk_ctr = ctr;   // the 4n-byte block; redraw candidates follow at ctr + 1 ..
+        ctr++;
+        const bool speculate = wg_pool && A.spec && !(A.debug_flags & 2);
+        if (speculate)
+        {
+            // Helper waves know every candidate counter up front (the bulk block consumes exactly
+            // one), so while the masters squeeze they precompute spec_cap candidates per ciphertext
+            // into HBM scratch; the masters then only walk that list.
+            if (master) lds_ctr[threadIdx.x] = ctr;
+            __syncthreads();
+            if (!master)
+            {
+                const uint32_t hthreads = blockDim.x - mthreads;
+                const size_t ct0        = (size_t)blockIdx.x * mthreads;
+                for (uint32_t idx = threadIdx.x - mthreads; idx < mthreads * A.spec_cap; idx += hthreads)
+                {
+                    const uint32_t ctl = idx % mthreads, off = idx / mthreads;
+                    if (ct0 + ctl >= A.B) continue;
+                    uint32_t tseed[16];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        uint4 v = *reinterpret_cast<const uint4 *>(lds_seed + ctl * 16 + 4 * i);
+                        tseed[4 * i] = v.x, tseed[4 * i + 1] = v.y, tseed[4 * i + 2] = v.z, tseed[4 * i + 3] = v.w;
+                    }
+                    KeccakState cs;
+                    prng_absorb(cs, tseed, lds_ctr[ctl] + off);
+                    keccak_f1600_fresh(cs);
+                    A.spec[(ct0 + ctl) * A.spec_cap + off] = cs.lo[0];
+                }
+            }
+        }
         if (active)
         {
             KeccakState st;
-            prng_absorb(st, seed, ctr);
-            ctr++;
+            prng_absorb(st, seed, bulk_ctr);
 
             // reject test and reduction of one word: sample.c:50-56
             auto word = [&](uint32_t x, uint32_t idx) -> uint32_t {
@@ -183,6 +214,18 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
             k++;
             need--;
         };
+
+        if (speculate)
+        {
+            __syncthreads();  // helpers' candidates are in HBM/L2 (their vmcnt drained above)
+            const uint32_t *row = A.spec + b * (size_t)A.spec_cap;
+            for (uint32_t t = 0; t < A.spec_cap && need > 0; t++)
+            {
+                const uint32_t x = __hip_atomic_load(row + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ctr++;
+                if (x < bound) place(x);
+            }
+        }
 
         // Workgroup pool (helper waves present): same dealing scheme as below, but over all
         // 64*(masters+helpers) lanes of the workgroup, with seeds / counters / candidates passed
@@ -468,6 +511,7 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
     chain_geometry(A0.B, threads, grid_x, lds, &mw, !(A0.debug_flags & 8));
     UniformArgs A   = A0;
     A.master_waves  = mw;
+    if (A.debug_flags & 16) A.spec = nullptr;  // A/B: helper waves without speculation
     dim3 grid(grid_x), block(threads);
 #define SEAMD_LAUNCH_UNIFORM(L)                                                                  \
     (void)hipFuncSetAttribute((const void *)k_sample_uniform<L>,                                 \

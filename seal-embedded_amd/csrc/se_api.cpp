@@ -256,7 +256,7 @@ int se_amd_sample_uniform_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const 
     if (rc) return rc;
     const uint32_t np = (uint32_t)ctx->c.hp.nprimes;
     seamd::UniformArgs ua{d_seeds, d_ctr_in, d_ctr_out, d_out, ctx->c.d_rej, ctx->c.rej_cap,
-                          (uint32_t)B, 0, np, np, 0, ctx->c.debug_flags};
+                          (uint32_t)B, 0, np, np, ctx->c.d_spec, ctx->c.spec_cap, 0, ctx->c.debug_flags};
     SEAMD_HIP(seamd::launch_sample_uniform(ctx->c.dp, ua, as_stream(stream)));
     return SE_SUCCESS;
 }

@@ -40,7 +40,7 @@ Context::~Context()
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
-                    d_err,     d_ucodes, d_ctr,    d_rej, d_a};
+                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -68,7 +68,8 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipSetDevice(device));
     dp = to_dev_params(hp);
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
-    // rej_cap >= 3x the expected rejections per polynomial
+    // rej_cap >= 3x the expected rejections per polynomial; spec_cap ~ mean + >5 sigma of the draws
+    spec_cap = (uint32_t)(n <= 2048 ? 32 : n / 32);
 
     std::vector<uint16_t> inv;
     host_index_map(hp, index_map, inv);
@@ -118,16 +119,17 @@ int Context::ensure_scratch(size_t B)
     if (B <= scratch_cap) return 0;
     SEAMD_HIP(hipSetDevice(device));
     SEAMD_HIP(hipDeviceSynchronize());
-    void *old[] = {d_err, d_ucodes, d_ctr, d_rej};
+    void *old[] = {d_err, d_ucodes, d_ctr, d_rej, d_spec};
     for (void *p : old)
         if (p) (void)hipFree(p);
-    d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_rej = nullptr;
+    d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_rej = nullptr, d_spec = nullptr;
     scratch_cap    = 0;
     const size_t n = hp.n;
     SEAMD_HIP(hipMalloc((void **)&d_err, B * 2 * n));
     SEAMD_HIP(hipMalloc((void **)&d_ucodes, B * n));
     SEAMD_HIP(hipMalloc((void **)&d_ctr, B * sizeof(uint64_t)));
     SEAMD_HIP(hipMalloc((void **)&d_rej, B * (size_t)(rej_cap ? rej_cap : 1) * sizeof(uint32_t)));
+    SEAMD_HIP(hipMalloc((void **)&d_spec, B * (size_t)spec_cap * sizeof(uint32_t)));
     scratch_cap = B;
     return 0;
 }
@@ -221,7 +223,7 @@ int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, co
     EncArgs ea{nullptr, nullptr, nullptr, d_p0, d_p1, nullptr, nullptr, nullptr};
     for (uint32_t j = 0; j < np; j++)
     {
-        UniformArgs ua{d_seeds + 64, nullptr, nullptr, d_p1, d_rej, rej_cap, 1, j, j + 1, np, 0, 0};
+        UniformArgs ua{d_seeds + 64, nullptr, nullptr, d_p1, d_rej, rej_cap, 1, j, j + 1, np, d_spec, spec_cap, 0, 0};
         SEAMD_HIP(launch_sample_uniform(dp, ua, nullptr));
         SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, 1, nullptr));
     }
@@ -301,8 +303,8 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
         SEAMD_HIP(launch_sample_cbd(ca, cbd_stream));
         stage_end(cbd_stream);
         if (overlap) SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
-        UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np, 0,
-                       debug_flags};
+        UniformArgs ua{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, np, np,
+                       d_spec, spec_cap, 0, debug_flags};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
         stage_end(st);
@@ -335,7 +337,8 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     {
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
-                       j,             j + 1,               np,    0,           debug_flags};
+                       j,             j + 1,               np,    d_spec,      spec_cap,
+                       0,             debug_flags};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
         stage_end(st);

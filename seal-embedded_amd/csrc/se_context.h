@@ -43,6 +43,8 @@ struct Context
     int8_t *d_ucodes   = nullptr;  // [cap][n]
     uint64_t *d_ctr    = nullptr;  // [cap]
     uint32_t *d_rej    = nullptr;  // [cap][rej_cap]
+    uint32_t *d_spec   = nullptr;  // [cap][spec_cap] speculative redraw candidates (helper waves)
+    uint32_t spec_cap  = 128;
     uint32_t *d_a      = nullptr;  // [a_cap][np][n]: `a` when the caller does not want c1 back
     size_t a_cap       = 0;
     size_t scratch_cap = 0;

@@ -79,9 +79,10 @@ def test_sample_uniform_vs_oracle(env, shape):
             row.append(a)
         exp.append(row)
         ectr.append(ctr)
-    # flags 0: helper waves pool the redraw phase over the workgroup (the small-batch shape);
-    # flags 8: wave-local redraw phase (the shape a full 65 536 batch runs)
-    for flags in (0, 8):
+    # flags 0: helper waves precompute redraw candidates during the squeeze (small-batch shape);
+    # flags 16: helper waves only pool the redraw phase; flags 8: wave-local redraw phase (the
+    # shape a full 65 536 batch runs)
+    for flags in (0, 8, 16):
         ctx = env["pkg"].Context(n, npr)
         ctx.set_debug_flags(flags)
         out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
@@ -132,7 +133,7 @@ def test_sample_uniform_reject_list_overflow_path(env):
         for j in range(npr):
             exp[b, j], ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
     for cap in (0, 1, 7, 64):
-        for flags in (0, 8):          # with and without the small-batch helper waves
+        for flags in (0, 8, 16):      # speculating helpers / no helpers / pooling-only helpers
             ctx = env["pkg"].Context(n, npr)
             ctx.set_reject_list_capacity(cap)
             ctx.set_debug_flags(flags)

@@ -21,12 +21,12 @@ for (n, npr, B) in ((16384, 6, 32768), (4096, 3, 16384), (4096, 3, 4096)):
     ss_np, sd_np = V.bench_seeds(B)
     ss, sd = torch.from_numpy(ss_np).to(dev), torch.from_numpy(sd_np).to(dev)
     c0 = torch.empty((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.empty_like(c0)
-    for ov, sp, fl in ((1, 1, 8), (1, 1, 0), (1, 0, 0)):
+    for ov, sp, fl in ((1, 1, 8), (1, 1, 16), (1, 1, 0)):
         ctx.set_pipeline(ov, sp); ctx.set_debug_flags(fl)
         t = timed(lambda: ctx.encrypt_sym(vals, ss, sd, c0, c1))
         ctx.set_profiling(True); ctx.stage_ms(True)
         for _ in range(2): ctx.encrypt_sym(vals, ss, sd, c0, c1)
         torch.cuda.synchronize(); st = {k: round(v[0] / 2, 2) for k, v in ctx.stage_ms(True).items() if v[1]}
         ctx.set_profiling(False)
-        print(f"n={n} np={npr} B={B} overlap={ov} split={sp} helpers={0 if fl else 1}: {t:.2f} ms  ({B/t:.1f}k ct/s)  {st}", flush=True)
+        print(f"n={n} np={npr} B={B} overlap={ov} split={sp} flags={fl} (8 = no helpers, 16 = helpers w/o speculation, 0 = default): {t:.2f} ms  ({B/t:.1f}k ct/s)  {st}", flush=True)
     ctx.close(); del c0, c1, vals
