@@ -47,6 +47,38 @@ DESCR = {
 }
 
 
+def bench_values_device(B, n, dev, seed=0xC0FFEE, first=0):
+    """tests/vectors.py::bench_values evaluated on the GPU (same splitmix64 counter generator,
+    int64 arithmetic wraps like uint64); checked against the numpy version on the first rows."""
+    import torch
+    import vectors as V
+
+    def s64(c):
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    import numpy as np
+    # byte -> float through a table built by numpy (GPU float division need not be correctly rounded)
+    table = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(-10.0)).to(dev)
+    out = torch.empty((B, n // 2), dtype=torch.float32, device=dev)
+    cols = torch.arange(n // 2, dtype=torch.int64, device=dev)[None, :]
+    step = 8192
+    for lo in range(0, B, step):
+        hi = min(B, lo + step)
+        idx = torch.arange(first + lo, first + hi, dtype=torch.int64, device=dev)[:, None] * (n // 2) + cols
+        z = (idx ^ s64(seed)) + s64(0x9E3779B97F4A7C15)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        out[lo:hi] = table[lsr(z, 56)]
+    k = min(B, 3)
+    ref = torch.from_numpy(V.bench_values(k, n, seed=seed, first=first)).to(dev)
+    assert bool((out[:k] == ref).all()), "device input generator disagrees with tests/vectors.py"
+    return out
+
+
 def cpu_baseline(n, npr, mode, budget_s=12.0):
     """Reference CPU path on this box's host cores over a bounded sample of the same workload
     (region = encode + sampler init + per-prime encrypt, keys resident; bench_sym.c:96-130)."""
@@ -159,7 +191,7 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before timing; rank r owns batch block r ----------
     first = rank * B
-    vals = torch.from_numpy(V.bench_values(B, n, first=first)).to(dev)
+    vals = bench_values_device(B, n, dev, first=first)
     ss_np, sd_np = V.bench_seeds(B, first=first)
     ss, sd = torch.from_numpy(ss_np).to(dev), torch.from_numpy(sd_np).to(dev)
     c0 = torch.empty((B, npr, n), dtype=torch.int32, device=dev)

@@ -31,12 +31,16 @@ def bench_values(B, n, seed=0xC0FFEE, first=0):
     """float32[B][n/2], i.i.d. (random byte) / -10 in [-25.5, 0] -- the distribution the
     reference bench uses (device/bench/bench_sym.c:92, bench_common.h:162-171).
     Element (b, i) depends only on (seed, first+b, i)."""
+    out = np.empty((B, n // 2), dtype=np.float32)
+    cols = np.arange(n // 2, dtype=np.uint64)[None, :]
+    step = 2048                      # rows per block: bounds the temporary uint64 arrays to ~100 MB
     with np.errstate(over="ignore"):
-        idx = (np.arange(first, first + B, dtype=np.uint64)[:, None] * np.uint64(n // 2) +
-               np.arange(n // 2, dtype=np.uint64)[None, :])
-        r = splitmix64(idx ^ np.uint64(seed))
-    byte = (r >> np.uint64(56)).astype(np.float32)
-    return (byte / np.float32(-10.0)).astype(np.float32)
+        for lo in range(0, B, step):
+            hi = min(B, lo + step)
+            idx = np.arange(first + lo, first + hi, dtype=np.uint64)[:, None] * np.uint64(n // 2) + cols
+            r = splitmix64(idx ^ np.uint64(seed))
+            out[lo:hi] = (r >> np.uint64(56)).astype(np.float32) / np.float32(-10.0)
+    return out
 
 
 def derive_seeds(label, B, first=0):
