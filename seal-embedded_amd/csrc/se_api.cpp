@@ -20,6 +20,10 @@ const std::string &last_error();
 }
 using seamd::Context;
 
+static_assert(seamd::kErrInvalid == SE_ERR_INVALD_ARGUMENT && seamd::kErrNoDevice == SE_ERR_NO_DEVICE &&
+                  seamd::kErrHip == SE_ERR_HIP && seamd::kErrNoKey == SE_ERR_NO_KEY,
+              "internal error codes must match the public header");
+
 struct se_amd_ctx
 {
     Context c;

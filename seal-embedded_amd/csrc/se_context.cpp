@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char *what)
     char buf[512];
     snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
     set_last_error(buf);
-    return -1001;  // SE_ERR_HIP
+    return kErrHip;
 }
 
 Context::~Context()
@@ -51,18 +51,18 @@ int Context::init(size_t n, size_t nprimes, int dev)
     if (rc != 0)
     {
         set_last_error("unsupported parameter set (degree, nprimes)");
-        return -22;
+        return kErrInvalid;
     }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     {
         set_last_error("no HIP device available: this library has no CPU path");
-        return -19;  // SE_ERR_NO_DEVICE
+        return kErrNoDevice;
     }
     if (dev < 0 || dev >= count)
     {
         set_last_error("device index out of range");
-        return -22;
+        return kErrInvalid;
     }
     device = dev;
     SEAMD_HIP(hipSetDevice(device));
@@ -149,7 +149,7 @@ int Context::set_secret_key(const uint8_t *sk_packed)
             if (code > 2)
             {
                 set_last_error("secret key holds an invalid 2-bit code (3)");
-                return -22;
+                return kErrInvalid;
             }
             expanded[j * n + i] = code + (code == 0 ? hp.q[j] : 0u) - 1u;
         }
@@ -177,7 +177,7 @@ int Context::set_public_key(const uint32_t *pk0, const uint32_t *pk1)
             if (pk0[j * n + i] >= hp.q[j] || pk1[j * n + i] >= hp.q[j])
             {
                 set_last_error("public key coefficient not reduced modulo its prime");
-                return -22;
+                return kErrInvalid;
             }
     uint32_t *d_tmp = nullptr;
     SEAMD_HIP(hipMalloc((void **)&d_tmp, 2 * np * n * sizeof(uint32_t)));
@@ -276,10 +276,10 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     if (!have_sk)
     {
         set_last_error("symmetric encryption needs a secret key (se_amd_set_secret_key)");
-        return -1002;
+        return kErrNoKey;
     }
     if (B == 0) return 0;
-    if (!d_values || !d_share_seeds || !d_seeds || !d_c0 || !d_c1) return -22;
+    if (!d_values || !d_share_seeds || !d_seeds || !d_c0 || !d_c1) return kErrInvalid;
     SEAMD_HIP(hipSetDevice(device));
     int rc = ensure_scratch(B);
     if (rc) return rc;
@@ -372,10 +372,10 @@ int Context::encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seed
     if (!have_pk)
     {
         set_last_error("asymmetric encryption needs a public key (se_amd_set_public_key)");
-        return -1002;
+        return kErrNoKey;
     }
     if (B == 0) return 0;
-    if (!d_values || !d_seeds || !d_c0 || !d_c1) return -22;
+    if (!d_values || !d_seeds || !d_c0 || !d_c1) return kErrInvalid;
     SEAMD_HIP(hipSetDevice(device));
     int rc = ensure_scratch(B);
     if (rc) return rc;
@@ -432,7 +432,7 @@ int Context::encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_
                         uint8_t *d_status, hipStream_t st)
 {
     if (B == 0) return 0;
-    if (!d_values || !d_out) return -22;
+    if (!d_values || !d_out) return kErrInvalid;
     SEAMD_HIP(hipSetDevice(device));
     EncArgs ea{d_values, nullptr, nullptr, d_out, nullptr, nullptr, d_pte, d_status};
     stage_begin(3, st);

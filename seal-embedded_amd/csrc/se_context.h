@@ -11,6 +11,12 @@
 
 namespace seamd {
 
+// error codes of include/seal_embedded_amd.h (kept numerically identical; checked in se_api.cpp)
+constexpr int kErrInvalid  = -22;    // SE_ERR_INVALD_ARGUMENT
+constexpr int kErrNoDevice = -19;    // SE_ERR_NO_DEVICE
+constexpr int kErrHip      = -1001;  // SE_ERR_HIP
+constexpr int kErrNoKey    = -1002;  // SE_ERR_NO_KEY
+
 constexpr int kStageCount = 6;  // cbd, uniform, ternary, encode_encrypt (fused), encode_rns, ntt_fuse
 
 struct StageEvent
