@@ -10,6 +10,7 @@ ubench2) ( timeout 120 ./tools/ubench2 ) > gpurun_out/ubench2.log 2>&1; cat gpur
 tests) ( timeout 2400 python -m pytest tests -m gpu -q --tb=short --timeout=900 ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
 bench) ( timeout 900 python bench.py --steps 10 --warmup 2 ) > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log; tail -3 gpurun_out/bench.log;;
 dist1) ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --batch 16384 --no-cpu-baseline --gather ) > gpurun_out/dist1.log 2>&1; tail -3 gpurun_out/dist1.log; ( WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --batch 8192 --no-cpu-baseline --gather ) > gpurun_out/dist1b.log 2>&1; tail -2 gpurun_out/dist1b.log;;
+benchc5) for w in c5; do ( timeout 900 python bench.py --steps 5 --warmup 1 --workload $w --no-cpu-baseline ) > gpurun_out/bench_$w.log 2>&1; tail -1 gpurun_out/bench_$w.log; done;;
 benchc3) for w in c3; do ( timeout 900 python bench.py --steps 5 --warmup 1 --workload $w --no-cpu-baseline ) > gpurun_out/bench_$w.log 2>&1; tail -1 gpurun_out/bench_$w.log; done;;
 benchall) for w in c3 c5 c4 c1; do ( timeout 900 python bench.py --steps 5 --warmup 1 --workload $w --no-cpu-baseline ) > gpurun_out/bench_$w.log 2>&1; tail -1 gpurun_out/bench_$w.log; done;;
 prof) cd /tmp && rm -rf /tmp/prof && ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline ) > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/prof; find /tmp/prof -name "*.csv" -size -2000k -exec cp {} gpurun_out/prof/ \; ; ls gpurun_out/prof; tail -3 gpurun_out/prof.log; for f in gpurun_out/prof/*kernel_stats*; do head -12 $f; done;;
