@@ -260,6 +260,9 @@ int se_amd_stage_ms(se_amd_ctx *ctx, float *ms /*[SE_AMD_STAGE_COUNT]*/,
 /* test hook: capacity of the per-ciphertext rejection list of the uniform sampler (default 256);
  * tiny values force the overflow path. */
 int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
+/* test hook: redraw candidates the helper waves precompute per ciphertext (default n/32); tiny
+ * values force the pooled fallback for the remaining draws. */
+int se_amd_set_speculation_capacity(se_amd_ctx *ctx, uint32_t cap);
 /* Pre-allocate the internal scratch for batches of up to B plaintexts (keeps hipMalloc out of
  * the first timed call). */
 int se_amd_reserve(se_amd_ctx *ctx, size_t B);

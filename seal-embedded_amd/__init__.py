@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_pack_ternary_host", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
     "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
-    "se_amd_set_reject_list_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -112,6 +112,7 @@ def lib():
     L.se_amd_set_profiling.argtypes = [vp, i32]
     L.se_amd_stage_ms.argtypes = [vp, vp, vp, i32]
     L.se_amd_set_reject_list_capacity.argtypes = [vp, u32]
+    L.se_amd_set_speculation_capacity.argtypes = [vp, u32]
     L.se_amd_reserve.argtypes = [vp, sz]
     L.se_amd_set_debug_flags.argtypes = [vp, u32]
     L.se_amd_set_pipeline.argtypes = [vp, i32, i32]
@@ -332,6 +333,10 @@ class Context:
 
     def set_debug_flags(self, flags):
         _check(self.L.se_amd_set_debug_flags(self.h, flags), "se_amd_set_debug_flags")
+
+    def set_speculation_capacity(self, cap):
+        _check(self.L.se_amd_set_speculation_capacity(self.h, cap),
+               "se_amd_set_speculation_capacity")
 
     def reserve(self, B):
         _check(self.L.se_amd_reserve(self.h, B), "se_amd_reserve")

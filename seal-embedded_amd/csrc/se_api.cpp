@@ -341,6 +341,14 @@ int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split)
     return SE_SUCCESS;
 }
 
+int se_amd_set_speculation_capacity(se_amd_ctx *ctx, uint32_t cap)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    ctx->c.spec_cap    = cap ? cap : 1;
+    ctx->c.scratch_cap = 0;  // force re-allocation with the new stride
+    return SE_SUCCESS;
+}
+
 int se_amd_reserve(se_amd_ctx *ctx, size_t B)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;

@@ -143,6 +143,32 @@ def test_sample_uniform_reject_list_overflow_path(env):
             assert (host_u32(out) == exp).all(), (cap, flags)
 
 
+def test_sample_uniform_speculation_shortfall_path(env):
+    """Helper waves precompute spec_cap redraw candidates per ciphertext; when a ciphertext needs
+    more, the rest goes through the pooled loop.  Forced here with tiny capacities."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 130
+    o = Oracle(n, npr)
+    seeds = seeds_np(B, "uni-spec")
+    exp = np.zeros((B, npr, n), dtype=np.uint32)
+    ectr = []
+    for b in range(B):
+        ctr = 0
+        for j in range(npr):
+            exp[b, j], ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
+        ectr.append(ctr)
+    for cap in (1, 8, 70, 90):
+        ctx = env["pkg"].Context(n, npr)
+        ctx.set_speculation_capacity(cap)
+        out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+        ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+        ctx.sample_uniform(dev_t(env, seeds), out, ctr_out=ctr_out)
+        torch.cuda.synchronize()
+        assert (host_u32(out) == exp).all(), cap
+        assert [int(x) for x in ctr_out.cpu().numpy()] == ectr, cap
+
+
 @pytest.mark.parametrize("n", [1024, 2048, 4096, 16384])
 def test_sample_ternary_and_cbd_vs_oracle(env, n):
     from oracle.pyoracle import Oracle
