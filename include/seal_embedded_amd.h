@@ -263,6 +263,9 @@ int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
 /* test hook: redraw candidates the helper waves precompute per ciphertext (default n/32); tiny
  * values force the pooled fallback for the remaining draws. */
 int se_amd_set_speculation_capacity(se_amd_ctx *ctx, uint32_t cap);
+/* test hook: ciphertexts per chunk of the host-pointer pipeline (0 = automatic: up to 16384, at most
+ * 4 GiB of output per chunk). */
+int se_amd_set_host_chunk(se_amd_ctx *ctx, size_t ciphertexts);
 /* Pre-allocate the internal scratch for batches of up to B plaintexts (keeps hipMalloc out of
  * the first timed call). */
 int se_amd_reserve(se_amd_ctx *ctx, size_t B);

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_pack_ternary_host", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
     "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
-    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -113,6 +113,7 @@ def lib():
     L.se_amd_stage_ms.argtypes = [vp, vp, vp, i32]
     L.se_amd_set_reject_list_capacity.argtypes = [vp, u32]
     L.se_amd_set_speculation_capacity.argtypes = [vp, u32]
+    L.se_amd_set_host_chunk.argtypes = [vp, sz]
     L.se_amd_reserve.argtypes = [vp, sz]
     L.se_amd_set_debug_flags.argtypes = [vp, u32]
     L.se_amd_set_pipeline.argtypes = [vp, i32, i32]
@@ -286,14 +287,25 @@ class Context:
         return out
 
     # ---- host-pointer wrappers (numpy in / numpy out)
-    def encrypt_sym_host(self, values, share_seeds, seeds, want_extra=False):
+    def _host_out(self, out, B):
+        """(c0, c1) host arrays: fresh, or the caller's (e.g. pinned) uint32[B][np][n] buffers."""
+        import numpy as np
+        if out is None:
+            c0 = np.zeros((B, self.np, self.n), dtype=np.uint32)
+            return c0, np.zeros_like(c0)
+        c0, c1 = out
+        for a in (c0, c1):
+            if a.dtype != np.uint32 or a.shape != (B, self.np, self.n) or not a.flags.c_contiguous:
+                raise ValueError("out buffers must be C-contiguous uint32[B][np][n]")
+        return c0, c1
+
+    def encrypt_sym_host(self, values, share_seeds, seeds, want_extra=False, out=None):
         import numpy as np
         v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1, self.n // 2)
         B = v.shape[0]
         ss = np.ascontiguousarray(share_seeds, dtype=np.uint8).reshape(B, 64)
         sd = np.ascontiguousarray(seeds, dtype=np.uint8).reshape(B, 64)
-        c0 = np.zeros((B, self.np, self.n), dtype=np.uint32)
-        c1 = np.zeros_like(c0)
+        c0, c1 = self._host_out(out, B)
         ntt_pte = np.zeros_like(c0) if want_extra else None
         pte = np.zeros((B, self.n), dtype=np.int64) if want_extra else None
         status = np.zeros(B, dtype=np.uint8)
@@ -302,13 +314,12 @@ class Context:
                                                    _ptr(status)), "se_amd_encrypt_sym_host")
         return dict(failed=rc, c0=c0, c1=c1, ntt_pte=ntt_pte, pte=pte, status=status)
 
-    def encrypt_asym_host(self, values, seeds, want_extra=False):
+    def encrypt_asym_host(self, values, seeds, want_extra=False, out=None):
         import numpy as np
         v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1, self.n // 2)
         B = v.shape[0]
         sd = np.ascontiguousarray(seeds, dtype=np.uint8).reshape(B, 64)
-        c0 = np.zeros((B, self.np, self.n), dtype=np.uint32)
-        c1 = np.zeros_like(c0)
+        c0, c1 = self._host_out(out, B)
         ntt_pte = np.zeros_like(c0) if want_extra else None
         pte = np.zeros((B, self.n), dtype=np.int64) if want_extra else None
         status = np.zeros(B, dtype=np.uint8)
@@ -337,6 +348,9 @@ class Context:
     def set_speculation_capacity(self, cap):
         _check(self.L.se_amd_set_speculation_capacity(self.h, cap),
                "se_amd_set_speculation_capacity")
+
+    def set_host_chunk(self, cts):
+        _check(self.L.se_amd_set_host_chunk(self.h, cts), "se_amd_set_host_chunk")
 
     def reserve(self, B):
         _check(self.L.se_amd_reserve(self.h, B), "se_amd_reserve")

@@ -14,11 +14,13 @@
 
 #include "../../include/seal_embedded_amd.h"
 #include "se_context.h"
+#include "se_hostpipe.h"
 
 namespace seamd {
 const std::string &last_error();
 }
 using seamd::Context;
+using seamd::HostPipe;
 
 static_assert(seamd::kErrInvalid == SE_ERR_INVALD_ARGUMENT && seamd::kErrNoDevice == SE_ERR_NO_DEVICE &&
                   seamd::kErrHip == SE_ERR_HIP && seamd::kErrNoKey == SE_ERR_NO_KEY,
@@ -356,22 +358,23 @@ int se_amd_reserve(se_amd_ctx *ctx, size_t B)
 }
 
 // ---- host-pointer wrappers ------------------------------------------------------------------
-namespace {
-struct DevBuf
+static int host_pipe(se_amd_ctx *ctx, HostPipe **out)
 {
-    void *p = nullptr;
-    ~DevBuf()
+    Context &c = ctx->c;
+    if (!c.host_pipe)
     {
-        if (p) (void)hipFree(p);
+        HostPipe *hp = new HostPipe();
+        int rc       = hp->init(c.device);
+        if (rc)
+        {
+            delete hp;
+            return rc;
+        }
+        c.host_pipe = hp;
     }
-    int alloc(size_t bytes)
-    {
-        if (bytes == 0) bytes = 1;
-        hipError_t e = hipMalloc(&p, bytes);
-        return e == hipSuccess ? 0 : seamd::hip_fail(e, "hipMalloc(host wrapper)");
-    }
-};
-}  // namespace
+    *out = c.host_pipe;
+    return 0;
+}
 
 static int run_host(se_amd_ctx *ctx, bool asym, const float *values, size_t B,
                     const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1,
@@ -380,42 +383,25 @@ static int run_host(se_amd_ctx *ctx, bool asym, const float *values, size_t B,
     if (!ctx || !values || !seeds || !c0 || !c1 || (!asym && !share_seeds))
         return SE_ERR_INVALD_ARGUMENT;
     if (B == 0) return SE_SUCCESS;
-    Context &c     = ctx->c;
-    const size_t n = c.hp.n, np = c.hp.nprimes;
-    SEAMD_HIP(hipSetDevice(c.device));
-    DevBuf dv, dss, dsd, d0, d1, dnp, dpt, dst;
-    int rc;
-    if ((rc = dv.alloc(B * (n / 2) * sizeof(float)))) return rc;
-    if ((rc = dsd.alloc(B * 64))) return rc;
-    if ((rc = d0.alloc(B * np * n * 4))) return rc;
-    if ((rc = d1.alloc(B * np * n * 4))) return rc;
-    if ((rc = dst.alloc(B))) return rc;
-    if (!asym && (rc = dss.alloc(B * 64))) return rc;
-    if (ntt_pte && (rc = dnp.alloc(B * np * n * 4))) return rc;
-    if (pte && (rc = dpt.alloc(B * n * 8))) return rc;
-    SEAMD_HIP(hipMemcpy(dv.p, values, B * (n / 2) * sizeof(float), hipMemcpyHostToDevice));
-    SEAMD_HIP(hipMemcpy(dsd.p, seeds, B * 64, hipMemcpyHostToDevice));
-    if (!asym) SEAMD_HIP(hipMemcpy(dss.p, share_seeds, B * 64, hipMemcpyHostToDevice));
-    if (asym)
-        rc = c.encrypt_asym((const float *)dv.p, B, (const uint8_t *)dsd.p, (uint32_t *)d0.p,
-                            (uint32_t *)d1.p, (uint32_t *)dnp.p, (int64_t *)dpt.p, (uint8_t *)dst.p,
-                            nullptr);
-    else
-        rc = c.encrypt_sym((const float *)dv.p, B, (const uint8_t *)dss.p, (const uint8_t *)dsd.p,
-                           (uint32_t *)d0.p, (uint32_t *)d1.p, (uint32_t *)dnp.p, (int64_t *)dpt.p,
-                           (uint8_t *)dst.p, nullptr);
+    if (asym ? !ctx->c.have_pk : !ctx->c.have_sk)
+    {
+        seamd::set_last_error(asym ? "no public key loaded" : "no secret key loaded");
+        return SE_ERR_NO_KEY;
+    }
+    HostPipe *hp;
+    int rc = host_pipe(ctx, &hp);
     if (rc) return rc;
-    SEAMD_HIP(hipDeviceSynchronize());
-    SEAMD_HIP(hipMemcpy(c0, d0.p, B * np * n * 4, hipMemcpyDeviceToHost));
-    SEAMD_HIP(hipMemcpy(c1, d1.p, B * np * n * 4, hipMemcpyDeviceToHost));
-    if (ntt_pte) SEAMD_HIP(hipMemcpy(ntt_pte, dnp.p, B * np * n * 4, hipMemcpyDeviceToHost));
-    if (pte) SEAMD_HIP(hipMemcpy(pte, dpt.p, B * n * 8, hipMemcpyDeviceToHost));
-    std::vector<uint8_t> st(B);
-    SEAMD_HIP(hipMemcpy(st.data(), dst.p, B, hipMemcpyDeviceToHost));
-    int failed = 0;
-    for (size_t i = 0; i < B; i++) failed += st[i] ? 0 : 1;
-    if (status) memcpy(status, st.data(), B);
-    return failed;
+    return hp->run(ctx->c, asym, values, B, share_seeds, seeds, c0, c1, ntt_pte, pte, status);
+}
+
+int se_amd_set_host_chunk(se_amd_ctx *ctx, size_t ciphertexts)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    HostPipe *hp;
+    int rc = host_pipe(ctx, &hp);
+    if (rc) return rc;
+    hp->chunk_override = ciphertexts;
+    return SE_SUCCESS;
 }
 
 int se_amd_encrypt_sym_host(se_amd_ctx *ctx, const float *values, size_t B,

@@ -7,6 +7,7 @@
 //                                      counter base) -> k_encode_encrypt
 //   encode-only (BASELINE config 5):  k_encode_encrypt<EncodeOnly>
 #include "se_context.h"
+#include "se_hostpipe.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -29,6 +30,7 @@ int hip_fail(hipError_t e, const char *what)
 Context::~Context()
 {
     (void)hipSetDevice(device);
+    delete host_pipe;
     for (auto &ev : events)
     {
         (void)hipEventDestroy(ev.start);

@@ -19,6 +19,8 @@ constexpr int kErrNoKey    = -1002;  // SE_ERR_NO_KEY
 
 constexpr int kStageCount = 6;  // cbd, uniform, ternary, encode_encrypt (fused), encode_rns, ntt_fuse
 
+struct HostPipe;
+
 struct StageEvent
 {
     int stage;
@@ -68,6 +70,9 @@ struct Context
                            // form wins whenever the uniform sampler's chains leave SIMDs empty (fewer
                            // than 4 chain waves per CU) or the fused kernel spills (n >= 8192);
                            // at n = 4096, B = 65536 both measure the same and fused moves less data
+
+    // host-pointer entry points: chunked PCIe pipeline (se_hostpipe.h), created on first use
+    HostPipe *host_pipe = nullptr;
 
     // profiling
     bool profiling = false;

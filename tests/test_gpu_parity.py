@@ -143,6 +143,65 @@ def test_sample_uniform_reject_list_overflow_path(env):
             assert (host_u32(out) == exp).all(), (cap, flags)
 
 
+@pytest.mark.parametrize("asym", [False, True])
+def test_host_pipeline_chunks_and_pinned_outputs(env, asym):
+    """The host-pointer entry is a chunked PCIe pipeline (se_hostpipe.cpp): forced small chunks with
+    a ragged tail, more chunks than device slots, pageable (staged through the pinned ring) and
+    pinned (direct DMA) destinations all have to give the device-pointer path's bytes."""
+    torch = env["torch"]
+    n, npr, B = 1024, 1, 300
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    if asym:
+        ctx.set_public_key(*ctx.gen_public_key(sk, bytes(range(64)), bytes(range(64, 128))))
+    vals = V.bench_values(B, n, seed=99)
+    ss, sd = V.bench_seeds(B, first=500)
+    run = (lambda **kw: ctx.encrypt_asym_host(vals, sd, **kw)) if asym else \
+          (lambda **kw: ctx.encrypt_sym_host(vals, ss, sd, **kw))
+    ref = run(want_extra=True)                       # automatic chunking: one chunk
+    assert ref["failed"] == 0 and ref["status"].all()
+    d0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    d1 = torch.zeros_like(d0)
+    if asym:
+        ctx.encrypt_asym(dev_t(env, vals), dev_t(env, sd), d0, d1)
+    else:
+        ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), d0, d1)
+    torch.cuda.synchronize()
+    assert (host_u32(d0) == ref["c0"]).all() and (host_u32(d1) == ref["c1"]).all()
+    for chunk in (64, 7, 299):
+        ctx.set_host_chunk(chunk)
+        r = run(want_extra=True)
+        for k in ("c0", "c1", "ntt_pte", "pte", "status"):
+            assert (r[k] == ref[k]).all(), (chunk, k)
+    # pinned destinations: direct DMA, no staging ring
+    p0 = torch.zeros((B, npr, n), dtype=torch.int32).pin_memory()
+    p1 = torch.zeros((B, npr, n), dtype=torch.int32).pin_memory()
+    ctx.set_host_chunk(64)
+    r = run(out=(p0.numpy().view(np.uint32), p1.numpy().view(np.uint32)))
+    assert (r["c0"] == ref["c0"]).all() and (r["c1"] == ref["c1"]).all()
+    ctx.set_host_chunk(0)
+
+
+def test_host_pipeline_large_pieces(env):
+    """Outputs larger than one 64 MiB ring piece and more pieces than ring entries (n=4096, 3 primes,
+    B=4096 -> 192 MiB per component per chunk, two chunks)."""
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 4096
+    ctx = env["pkg"].Context(n, npr)
+    ctx.set_secret_key(V.secret_key(n))
+    vals = V.bench_values(B, n, seed=5)
+    ss, sd = V.bench_seeds(B)
+    d0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    d1 = torch.zeros_like(d0)
+    ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), d0, d1)
+    torch.cuda.synchronize()
+    ctx.set_host_chunk(2048)
+    r = ctx.encrypt_sym_host(vals, ss, sd)
+    assert r["failed"] == 0
+    assert (r["c0"] == host_u32(d0)).all() and (r["c1"] == host_u32(d1)).all()
+
+
 def test_sample_uniform_speculation_shortfall_path(env):
     """Helper waves precompute spec_cap redraw candidates per ciphertext; when a ciphertext needs
     more, the rest goes through the pooled loop.  Forced here with tiny capacities."""
