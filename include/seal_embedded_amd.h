@@ -123,7 +123,9 @@ void se_cleanup(SE_PARMS *se_parms);
 
 /* New beside them: batched host-pointer entry on the handle se_setup returned.
  * values [B][n/2] float; share_seeds [B][64] (ignored for asymmetric; may be NULL then);
- * seeds [B][64]; c0, c1 [B][np][n] uint32 out.  Returns SE_SUCCESS, or the number (>0) of
+ * seeds [B][64]; c0, c1 [B][np][n] uint32 out.  Symmetric only: c1 may be NULL -- seed-compressed
+ * form, the receiver re-expands c1 = a from share_seeds (se_amd_expand_c1_device), which halves
+ * the bytes crossing PCIe.  Returns SE_SUCCESS, or the number (>0) of
  * plaintexts whose encoding overflowed int64 (their records are unspecified), or SE_ERR_*. */
 int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
                      const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1);
@@ -181,7 +183,9 @@ int se_amd_encrypt_asym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
 int se_amd_encode_ntt_device(se_amd_ctx *ctx, const float *d_values, size_t B, uint32_t *d_out,
                              int64_t *d_pte, uint8_t *d_status, void *stream);
 
-/* Host-pointer convenience wrappers (H2D, run, D2H, synchronous). */
+/* Host-pointer entries: synchronous; a chunked pipeline (compute || D2H through a pinned staging
+ * ring, or DMA straight into pinned/registered caller memory) that runs at the PCIe link rate.
+ * c1 may be NULL for the symmetric form (seed-compressed: only c0 is returned). */
 int se_amd_encrypt_sym_host(se_amd_ctx *ctx, const float *values, size_t B,
                             const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0,
                             uint32_t *c1, uint32_t *ntt_pte, int64_t *pte, uint8_t *status);

@@ -299,13 +299,16 @@ class Context:
                 raise ValueError("out buffers must be C-contiguous uint32[B][np][n]")
         return c0, c1
 
-    def encrypt_sym_host(self, values, share_seeds, seeds, want_extra=False, out=None):
+    def encrypt_sym_host(self, values, share_seeds, seeds, want_extra=False, out=None,
+                         seed_compressed=False):
         import numpy as np
         v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1, self.n // 2)
         B = v.shape[0]
         ss = np.ascontiguousarray(share_seeds, dtype=np.uint8).reshape(B, 64)
         sd = np.ascontiguousarray(seeds, dtype=np.uint8).reshape(B, 64)
         c0, c1 = self._host_out(out, B)
+        if seed_compressed:
+            c1 = None                  # only c0 crosses PCIe; c1 = expand_c1(share_seeds)
         ntt_pte = np.zeros_like(c0) if want_extra else None
         pte = np.zeros((B, self.n), dtype=np.int64) if want_extra else None
         status = np.zeros(B, dtype=np.uint8)

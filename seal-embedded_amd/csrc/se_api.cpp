@@ -380,7 +380,7 @@ static int run_host(se_amd_ctx *ctx, bool asym, const float *values, size_t B,
                     const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1,
                     uint32_t *ntt_pte, int64_t *pte, uint8_t *status)
 {
-    if (!ctx || !values || !seeds || !c0 || !c1 || (!asym && !share_seeds))
+    if (!ctx || !values || !seeds || !c0 || (asym && !c1) || (!asym && !share_seeds))
         return SE_ERR_INVALD_ARGUMENT;
     if (B == 0) return SE_SUCCESS;
     if (asym ? !ctx->c.have_pk : !ctx->c.have_sk)

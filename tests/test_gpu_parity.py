@@ -180,6 +180,9 @@ def test_host_pipeline_chunks_and_pinned_outputs(env, asym):
     ctx.set_host_chunk(64)
     r = run(out=(p0.numpy().view(np.uint32), p1.numpy().view(np.uint32)))
     assert (r["c0"] == ref["c0"]).all() and (r["c1"] == ref["c1"]).all()
+    if not asym:                                     # seed-compressed host form: c0 only
+        r = ctx.encrypt_sym_host(vals, ss, sd, seed_compressed=True)
+        assert r["c1"] is None and (r["c0"] == ref["c0"]).all()
     ctx.set_host_chunk(0)
 
 
