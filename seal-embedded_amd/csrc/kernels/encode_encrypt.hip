@@ -285,8 +285,11 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
     }
 }
 
+// n = 16384: at most 96 VGPRs (5 waves per SIMD instead of the 4 the 1024-thread workgroup needs) so
+// that a workgroup fits beside the uniform sampler's chain waves (128 VGPRs, one wave per SIMD).
 template <int LOGN, int MODE>
-__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_ntt_fuse(DevParams P, DevTables T, EncArgs A,
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS)
+__attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 255) / 256))) void k_ntt_fuse(DevParams P, DevTables T, EncArgs A,
                                                                     int j)
 {
     using G            = XformGeom<LOGN>;
@@ -304,14 +307,17 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_ntt_fuse(DevParams
     uint32_t x[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = poly[(e << CTOP) + t];
-    // issue the epilogue operands now; they land while the NTT runs
+    // issue the epilogue operands now; they land while the NTT runs.  At n = 16384 only `a` (HBM) is
+    // prefetched; the L2-resident s_hat pairs are fetched after the NTT to stay within 96 VGPRs.
+    constexpr bool LATE_KEY = LOGN == 14;
     uint32_t a[16], w[16], wp[16];
     if constexpr (MODE == kModeSym)
     {
         load16(a, A.c1 + off);
-        load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+        if constexpr (!LATE_KEY) load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
     }
     ntt_tiles<LOGN>(x, T.ntt_rw + (size_t)2 * N * j, q, lds32, t);
+    if constexpr (MODE == kModeSym && LATE_KEY) load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
     if (A.ntt_pte) store16(A.ntt_pte + off, x);

@@ -488,7 +488,8 @@ __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const 
 // workgroup, which admits exactly one workgroup per CU: every CU gets the same number of waves
 // and the hardware deals a workgroup's waves round-robin over its 4 SIMDs.
 static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &lds_bytes,
-                           unsigned *master_waves = nullptr, bool allow_helpers = false)
+                           unsigned *master_waves = nullptr, bool allow_helpers = false,
+                           size_t fill_to = 8)
 {
     const size_t waves = (B + 63) / 64;
     size_t w           = (waves + 255) / 256;   // waves per CU if spread over 256 CUs
@@ -496,7 +497,7 @@ static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &
     if (w > 4) w = ((w + 3) / 4) * 4;           // beyond one per SIMD: whole multiples of 4
     if (w > 16) w = 16;
     size_t helpers = 0;
-    if (allow_helpers && w < 4) helpers = 8 - w;  // small batch: fill the CU to 2 waves per SIMD
+    if (allow_helpers && w < 4) helpers = fill_to - w;  // small batch: fill the CU to 2 waves per SIMD
     threads   = (unsigned)((w + helpers) * 64);   // with helper waves for the redraw phase
     grid      = (unsigned)((B + w * 64 - 1) / (w * 64));
     lds_bytes = 84 * 1024;
@@ -508,7 +509,7 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
     if (A0.B == 0) return hipSuccess;
     unsigned threads, grid_x, mw;
     size_t lds;
-    chain_geometry(A0.B, threads, grid_x, lds, &mw, !(A0.debug_flags & 8));
+    chain_geometry(A0.B, threads, grid_x, lds, &mw, !(A0.debug_flags & 8), A0.helper_fill ? A0.helper_fill : 8);
     UniformArgs A   = A0;
     A.master_waves  = mw;
     if (A.debug_flags & 16) A.spec = nullptr;  // A/B: helper waves without speculation

@@ -39,6 +39,8 @@ Context::~Context()
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_cbd) (void)hipEventDestroy(ev_cbd);
+    if (ev_enc) (void)hipEventDestroy(ev_enc);
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
@@ -93,6 +95,8 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    SEAMD_HIP(hipEventCreateWithFlags(&ev_cbd, hipEventDisableTiming));
+    SEAMD_HIP(hipEventCreateWithFlags(&ev_enc, hipEventDisableTiming));
     for (size_t j = 0; j < (size_t)kMaxPrimes; j++)
         SEAMD_HIP(hipEventCreateWithFlags(&ev_prime[j], hipEventDisableTiming));
     {
@@ -329,21 +333,42 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
         SEAMD_HIP(hipEventRecord(ev_fork, st));
         SEAMD_HIP(hipStreamWaitEvent(ax, ev_fork, 0));
     }
+    // n = 16384 (`late_encode`): the encode workgroup (136 KiB of LDS, 128 VGPRs x 16 waves) cannot
+    // share a CU with a chain workgroup, so on the auxiliary stream it would sit behind every U_j
+    // and drag all N_j with it (measured: no overlap at all).  There it runs on the main stream
+    // between U_0 and U_1, the chain workgroups carry 2 helper waves instead of 6 (one wave per SIMD,
+    // 128 VGPRs) and k_ntt_fuse<14> is held to 80 VGPRs, so an N_j workgroup fits beside U_{j+1}:
+    //   S : U_0 ► (wait cbd) encode_rns ► U_1 ──► U_2 ──► ... ► U_{np-1} ──────► N_{np-1}
+    //   A : cbd ─────────────────────────► N_0 ► (wait U_1) N_1 ► ...        ┘(join)
+    const bool late_encode   = overlap && hp.n >= 16384 && !(debug_flags & 128);
+    const uint32_t fill      = late_encode ? 4 : 0;  // leave VGPRs for the co-resident N_j workgroup
     stage_begin(0, ax);
     SEAMD_HIP(launch_sample_cbd(ca, ax));  // e, counters 0.. (ckks_sym.c:196)
     stage_end(ax);
-    stage_begin(4, ax);
-    SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, ax));
-    stage_end(ax);
+    if (late_encode)
+        SEAMD_HIP(hipEventRecord(ev_cbd, ax));
+    else
+    {
+        stage_begin(4, ax);
+        SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, ax));
+        stage_end(ax);
+    }
     for (uint32_t j = 0; j < np; j++)
     {
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
                        j,             j + 1,               np,    d_spec,      spec_cap,
-                       0,             debug_flags};
+                       0,             debug_flags,         fill};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
         stage_end(st);
+        if (late_encode && j == 0)
+        {
+            SEAMD_HIP(hipStreamWaitEvent(st, ev_cbd, 0));
+            stage_begin(4, st);
+            SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, st));
+            stage_end(st);
+        }
         if (j + 1 < np)
         {
             if (overlap)

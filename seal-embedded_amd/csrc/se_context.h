@@ -62,7 +62,7 @@ struct Context
     // second stream: the CBD error sampler runs beside the uniform sampler (different seeds, no
     // data dependency); joined before the fused encode+encrypt kernel.
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cbd = nullptr, ev_enc = nullptr;
     hipEvent_t ev_prime[kMaxPrimes] = {};
     bool overlap = true;   // run independent kernels on the auxiliary stream
     int split_mode = 2;    // symmetric path: 0 = fused kernel, 1 = per-prime software pipeline
