@@ -194,12 +194,17 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
         uint32_t k       = 0;  // rejected coefficients resolved so far
         uint32_t scanpos = 0;  // list-overflow path: next index to scan for a marker
 
-        // one accepted candidate x for this lane's k-th rejected coefficient
-        auto place = [&](uint32_t x) {
+        // one accepted candidate x for this lane's k-th rejected coefficient.  The position comes
+        // from the reject list; `hint` is that entry when the caller already fetched it (the list
+        // read is a dependent global load, so callers issue it ahead of the work that hides it).
+        auto list_entry = [&](uint32_t kk) -> uint32_t {
+            return __hip_atomic_load(mylist + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto place = [&](uint32_t x, bool have_hint, uint32_t hint) {
             uint32_t pos;
             if (k < A.rej_cap)
             {
-                pos = __hip_atomic_load(mylist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pos = have_hint ? hint : list_entry(k);
             }
             else
             {
@@ -214,16 +219,47 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
             k++;
             need--;
         };
+        // entry k of the list, fetched ahead (0 when there is none to fetch)
+        auto prefetch_entry = [&]() -> uint32_t {
+            return (need > 0 && k < A.rej_cap) ? list_entry(k) : 0u;
+        };
 
         if (speculate)
         {
             __syncthreads();  // helpers' candidates are in HBM/L2 (their vmcnt drained above)
             const uint32_t *row = A.spec + b * (size_t)A.spec_cap;
-            for (uint32_t t = 0; t < A.spec_cap && need > 0; t++)
+            uint32_t t = 0;
+            // four candidates and the next four list entries per round trip: the walk is a chain
+            // of dependent L2/HBM loads otherwise (~300 candidates per polynomial at n = 16384)
+            for (; t + 4 <= A.spec_cap && need > 0; t += 4)
+            {
+                uint32_t x[4], pos4[4];
+                const uint32_t k0 = k;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    x[i] = __hip_atomic_load(row + t + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    pos4[i] = (k0 + i < A.rej_cap && (uint32_t)i < need) ? list_entry(k0 + i) : 0u;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    if (need > 0)
+                    {
+                        ctr++;
+                        if (x[i] < bound)
+                        {
+                            const uint32_t a = k - k0;  // accepted so far in this group
+                            place(x[i], true, a == 0 ? pos4[0] : a == 1 ? pos4[1] : a == 2 ? pos4[2] : pos4[3]);
+                        }
+                    }
+                }
+            }
+            for (; t < A.spec_cap && need > 0; t++)
             {
                 const uint32_t x = __hip_atomic_load(row + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ctr++;
-                if (x < bound) place(x);
+                if (x < bound) place(x, false, 0u);
             }
         }
 
@@ -258,6 +294,8 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
                 uint4 v = *reinterpret_cast<const uint4 *>(lds_seed + target * 16 + 4 * i);
                 tseed[4 * i] = v.x, tseed[4 * i + 1] = v.y, tseed[4 * i + 2] = v.z, tseed[4 * i + 3] = v.w;
             }
+            const uint32_t hint = prefetch_entry();  // lands while the permutation runs
+            const uint32_t hk   = k;
             KeccakState cs;
             prng_absorb(cs, tseed, lds_ctr[target] + d);
             keccak_f1600_fresh(cs);
@@ -271,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
                 {
                     const uint32_t x = lds_cand[src];
                     ctr++;
-                    if (x < bound) place(x);
+                    if (x < bound) place(x, k == hk, hint);
                 }
             }
             __syncthreads();
@@ -290,6 +328,8 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
             const uint32_t target = rank2lane[(uint32_t)lane - d * R];
             __builtin_amdgcn_wave_barrier();
 
+            const uint32_t hint = prefetch_entry();  // lands while the permutation runs
+            const uint32_t hk   = k;
             uint32_t tseed[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) tseed[i] = (uint32_t)__shfl((int)seed[i], (int)target);
@@ -308,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
                 if (need > 0 && src < 64u)
                 {
                     ctr++;
-                    if (x < bound) place(x);
+                    if (x < bound) place(x, k == hk, hint);
                 }
             }
         }
