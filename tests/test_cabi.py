@@ -92,3 +92,14 @@ def test_pack_ternary_host_matches_reference_format(pkg):
     L.se_amd_pack_ternary_host(codes.ctypes.data_as(C.c_void_p), 8, out.ctypes.data_as(C.c_void_p))
     # MSB-first 2-bit fields (sample.c:61-87): 00 01 10 01 | 10 10 00 00
     assert list(out) == [0b00011001, 0b10100000]
+
+
+def test_examples_compile_as_plain_c(tmp_path):
+    """The public header is valid C11 and the example callers build with gcc -Wall -Werror
+    (compile only: linking needs the HIP runtime's GPU-side dependencies at run time)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("api_digest", "batch_encrypt"):
+        subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-c",
+                        os.path.join(root, "examples", name + ".c"), "-I" + os.path.join(root, "include"),
+                        "-o", str(tmp_path / (name + ".o"))], check=True)

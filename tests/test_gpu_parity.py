@@ -13,6 +13,8 @@ import pytest
 
 import vectors as V
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 SEED_A = hashlib.shake_256(b"golden-share").digest(64)
@@ -717,3 +719,81 @@ def test_reference_api_callback_stream(env, golden, tmp_path):
     finally:
         os.environ.pop("SE_AMD_REFERENCE_C1_ALIAS", None)
         os.environ.pop("SE_AMD_DATA_PATH", None)
+
+
+# --------------------------------------------------------------------------- C callers (examples/)
+def _build_example(name, tmp_path):
+    import subprocess
+    exe = tmp_path / name
+    lib = os.path.join(ROOT, "seal-embedded_amd", "lib")
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", os.path.join(ROOT, "examples", name + ".c"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lseal_embedded_amd",
+                    "-Wl,-rpath," + lib, "-o", str(exe)], check=True)
+    return exe
+
+
+def _key_dir(env, tmp_path, n, npr, asym):
+    data = tmp_path / f"adapter_output_data_{n}_{int(asym)}"
+    data.mkdir()
+    sk = V.secret_key(n)
+    sk.tofile(data / f"sk_{n}.dat")
+    if asym:
+        ctx = env["pkg"].Context(n, npr)
+        pk0, pk1 = ctx.gen_public_key(sk, SEED_PK, SEED_EP)
+        for j, q in enumerate(ctx.moduli()):
+            pk0[j].tofile(data / f"pk0_ntt_{n}_{q}.dat")
+            pk1[j].tofile(data / f"pk1_ntt_{n}_{q}.dat")
+        ctx.close()
+    return data
+
+
+@pytest.mark.parametrize("shape,mode", [((1024, 1), "sym"), ((4096, 3), "sym"), ((4096, 3), "asym"),
+                                        ((16384, 6), "sym")])
+def test_c_caller_of_reference_api_reproduces_reference_digest(env, golden, tmp_path, shape, mode):
+    """examples/api_digest.c is written against the reference's API only and linked against this
+    library with plain gcc; with SE_AMD_REFERENCE_C1_ALIAS=1 its callback byte stream has the FNV
+    digest the compiled reference produced for the same input (golden, made by make_golden.py)."""
+    import subprocess
+    n, npr = shape
+    exe = _build_example("api_digest", tmp_path)
+    data = _key_dir(env, tmp_path, n, npr, mode == "asym")
+    e = dict(os.environ, SE_AMD_DATA_PATH=str(data), SE_AMD_REFERENCE_C1_ALIAS="1")
+    out = subprocess.run([str(exe), str(n), str(npr), mode], env=e, check=True, capture_output=True,
+                         text=True, timeout=300).stdout
+    line = [l for l in out.splitlines() if l.startswith("ok=")][-1]
+    kv = dict(f.split("=") for f in line.split())
+    assert kv["ok"] == "1" and int(kv["callbacks"]) == 2 * npr and int(kv["bytes"]) == 8 * n * npr
+    assert kv["fnv1a64"] == golden["digests"]["shapes"][f"{n}x{npr}"][f"api_fnv1a64_{mode}"]
+
+
+def test_c_caller_of_batch_entry(env, tmp_path):
+    """examples/batch_encrypt.c: se_encrypt_batch from C with malloc'ed (pageable) buffers; the
+    records equal the oracle's per-ciphertext results in the reference's callback order."""
+    import subprocess
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    n, npr, B = 1024, 1, 5
+    exe = _build_example("batch_encrypt", tmp_path)
+    data = _key_dir(env, tmp_path, n, npr, False)
+    e = dict(os.environ, SE_AMD_DATA_PATH=str(data))
+    out = subprocess.run([str(exe), str(n), str(npr), str(B)], env=e, check=True, capture_output=True,
+                         text=True, timeout=300).stdout
+    kv = dict(f.split("=") for f in [l for l in out.splitlines() if l.startswith("failed=")][-1].split())
+    o = Oracle(n, npr)
+    sk = V.secret_key(n)
+    h = 0xcbf29ce484222325
+    first = None
+    for b in range(B):
+        i = np.arange(n // 2, dtype=np.uint64) + np.uint64(b)
+        with np.errstate(over="ignore"):
+            v = ((i * np.uint64(2654435761)) % np.uint64(100000)).astype(np.float64) / 1000 - 50
+        share = bytes((k + b) & 255 for k in range(64))
+        seed = bytes((255 - k + 3 * b) & 255 for k in range(64))
+        r = o.encrypt_sym(v.astype(np.float32), share, seed, sk)
+        for j in range(npr):
+            h = pyoracle.fnv1a64(r["c0"][j].tobytes(), h)
+            h = pyoracle.fnv1a64(r["c1"][j].tobytes(), h)
+        if b == 0:
+            first = h
+    assert kv["failed"] == "0"
+    assert kv["first"] == "%016x" % first and kv["all"] == "%016x" % h
