@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "seal_embedded_amd.h"
 
@@ -57,6 +58,19 @@ int main(int argc, char **argv)
     bool ok = se_encrypt_seeded(share_seed, seed, send_cb, v, n / 2 * sizeof(float), false, parms);
     printf("ok=%d callbacks=%zu bytes=%zu fnv1a64=%016llx\n", (int)ok, g_calls, g_bytes,
            (unsigned long long)g_hash);
+
+    /* optional: latency of the single-ciphertext call (argv[4] = repetitions) */
+    int reps = argc > 4 ? atoi(argv[4]) : 0;
+    if (reps > 0)
+    {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int r = 0; r < reps; r++)
+            ok = se_encrypt_seeded(share_seed, seed, send_cb, v, n / 2 * sizeof(float), false, parms) && ok;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        double ms = 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec);
+        printf("latency_ms_per_call=%.3f over %d calls\n", ms / reps, reps);
+    }
     se_cleanup(parms);
     free(v);
     return ok ? 0 : 1;
