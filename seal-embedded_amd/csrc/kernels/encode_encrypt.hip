@@ -123,6 +123,16 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                                                                           EncArgs A)
 {
     using G            = XformGeom<LOGN>;
+    // roots of the next pass requested before the LDS exchange: pays for the public-key kernel
+    // (2 waves/SIMD, registers to spare: 7.23 -> 6.91 ms); the symmetric kernel (3 waves/SIMD at the
+    // 168-VGPR cap) spills more with it (3.66 -> 3.74 ms) and the split kernels do not move
+    constexpr bool PREFETCH_ROOTS = LOGN <= 12 && MODE == kModeAsym;
+    auto ntt_fwd = [&](uint32_t(&v)[16], const uint32_t *rw, uint32_t qq, uint32_t *l, int tt) {
+        if constexpr (PREFETCH_ROOTS)
+            ntt_tiles_prefetch<LOGN>(v, rw, qq, l, tt);
+        else
+            ntt_tiles<LOGN>(v, rw, qq, l, tt);
+    };
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
                 uh[e]         = code + (code == 0 ? q : 0u) - 1u;
             }
-            ntt_tiles<LOGN>(uh, RW, q, lds32, t);
+            ntt_fwd(uh, RW, q, lds32, t);
             // c1 = pk1 . u_hat + NTT(e1)   (:251, :263-272)
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 int32_t e1 = A.err[b * 2 * N + N + (e << CTOP) + t];
                 x[e]       = (e1 < 0 ? q : 0u) + (uint32_t)e1;
             }
-            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            ntt_fwd(x, RW, q, lds32, t);
             {
                 uint32_t w[16], wp[16], out[16];
                 load16_pairs(w, wp, T.pk1, (size_t)j * N + 16 * t);
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
             reduce_signed16(m, x, q, crh, crl);
-            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            ntt_fwd(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             if (A.ntt_pte) store16(A.ntt_pte + off, x);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
             reduce_signed16(m, x, q, crh, crl);
-            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            ntt_fwd(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             if (A.ntt_pte) store16(A.ntt_pte + off, x);
