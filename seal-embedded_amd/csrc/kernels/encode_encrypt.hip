@@ -17,6 +17,8 @@
 // instead of once per ciphertext as the reference does -- same values, 1/2 of the NTT work.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../se_types.h"
 #include "kernel_args.h"
 #include "transform.cuh"
@@ -123,16 +125,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                                                                           EncArgs A)
 {
     using G            = XformGeom<LOGN>;
-    // roots of the next pass requested before the LDS exchange: pays for the public-key kernel
-    // (2 waves/SIMD, registers to spare: 7.23 -> 6.91 ms); the symmetric kernel (3 waves/SIMD at the
-    // 168-VGPR cap) spills more with it (3.66 -> 3.74 ms) and the split kernels do not move
-    constexpr bool PREFETCH_ROOTS = LOGN <= 12 && MODE == kModeAsym;
-    auto ntt_fwd = [&](uint32_t(&v)[16], const uint32_t *rw, uint32_t qq, uint32_t *l, int tt) {
-        if constexpr (PREFETCH_ROOTS)
-            ntt_tiles_prefetch<LOGN>(v, rw, qq, l, tt);
-        else
-            ntt_tiles<LOGN>(v, rw, qq, l, tt);
-    };
+    constexpr bool ASYM3 = LOGN <= 12;  // three-way NTT per prime (three LDS planes; spills at n = 8192)
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -175,7 +168,51 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         const size_t off   = (b * np + j) * N + 16 * t;  // this thread's 16 output coefficients
         uint32_t x[16];
 
-        if constexpr (MODE == kModeAsym)
+        if constexpr (MODE == kModeAsym && ASYM3)
+        {
+            // the three transforms of this prime side by side (ntt_tiles3): u_hat = NTT(expand(u))
+            // (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1), NTT(e1) (:263-272) and
+            // NTT(m + e0) (:280-284)
+            uint32_t uh[16], y[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
+                uh[e]         = code + (code == 0 ? q : 0u) - 1u;
+                int32_t e1    = A.err[b * 2 * N + N + (e << CTOP) + t];
+                y[e]          = (e1 < 0 ? q : 0u) + (uint32_t)e1;
+            }
+            reduce_signed16(m, x, q, crh, crl);
+            ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
+            {
+                // c1 = pk1 . u_hat + NTT(e1)   (:251)
+                uint32_t w[16], wp[16], out[16];
+                load16_pairs(w, wp, T.pk1, (size_t)j * N + 16 * t);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
+                    out[e]      = csub(pr + canon4(y[e], q, two_q), q);
+                }
+                store16(A.c1 + off, out);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+            if (A.ntt_pte) store16(A.ntt_pte + off, x);
+            {
+                // c0 = pk0 . u_hat + NTT(m + e0)   (:255)
+                uint32_t w[16], wp[16], out[16];
+                load16_pairs(w, wp, T.pk0, (size_t)j * N + 16 * t);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
+                    out[e]      = csub(pr + x[e], q);
+                }
+                store16(A.c0 + off, out);
+            }
+        }
+        else         if constexpr (MODE == kModeAsym)
         {
             // u_hat = NTT(expand(u))   (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1)
             uint32_t uh[16];
@@ -185,7 +222,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
                 uh[e]         = code + (code == 0 ? q : 0u) - 1u;
             }
-            ntt_fwd(uh, RW, q, lds32, t);
+            ntt_tiles<LOGN>(uh, RW, q, lds32, t);
             // c1 = pk1 . u_hat + NTT(e1)   (:251, :263-272)
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -193,7 +230,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 int32_t e1 = A.err[b * 2 * N + N + (e << CTOP) + t];
                 x[e]       = (e1 < 0 ? q : 0u) + (uint32_t)e1;
             }
-            ntt_fwd(x, RW, q, lds32, t);
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
             {
                 uint32_t w[16], wp[16], out[16];
                 load16_pairs(w, wp, T.pk1, (size_t)j * N + 16 * t);
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
             reduce_signed16(m, x, q, crh, crl);
-            ntt_fwd(x, RW, q, lds32, t);
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             if (A.ntt_pte) store16(A.ntt_pte + off, x);
@@ -227,7 +264,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
             reduce_signed16(m, x, q, crh, crl);
-            ntt_fwd(x, RW, q, lds32, t);
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             if (A.ntt_pte) store16(A.ntt_pte + off, x);
@@ -540,6 +577,8 @@ static hipError_t launch_enc(const DevParams &P, const DevTables &T, const EncAr
 {
     using G        = XformGeom<LOGN>;
     size_t shmem   = (size_t)G::SLOTS * sizeof(double);
+    // public-key kernel, n <= 4096: three u32 planes for the three-way NTT
+    const size_t shmem_asym = LOGN <= 12 ? std::max(shmem, (size_t)3 * G::SLOTS * sizeof(uint32_t)) : shmem;
     dim3 grid((unsigned)B), block(G::THREADS);
     switch (mode)
     {
@@ -550,8 +589,8 @@ static hipError_t launch_enc(const DevParams &P, const DevTables &T, const EncAr
             break;
         case kModeAsym:
             (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeAsym>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeAsym>), grid, block, shmem, st, P, T, A);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_asym);
+            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeAsym>), grid, block, shmem_asym, st, P, T, A);
             break;
         default:
             (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeEncodeOnly>,

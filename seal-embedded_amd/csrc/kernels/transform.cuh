@@ -153,54 +153,6 @@ __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
 // NTT pass: stages for local bits [B_LO, B_HI) of a tile at window C, descending.
 // RW = interleaved (root, shoup(root)) table of one prime.
 // ------------------------------------------------------------------------------------------
-// Root operands of one pass live in registers: 15 (root, shoup) pairs for a 4-stage pass, pair
-// (b, g) at slot (2^(3-b) - 1) + g.  Loading them is separate from using them so that the loads
-// of pass p+1 can be issued BEFORE the LDS exchange that follows pass p: register pressure is at
-// its lowest there (only the 16 points are live) and the L2 latency of the table (the roots of the
-// lower windows differ per lane, so they are vector loads) hides behind the exchange.
-template <int LOGN, int C, int B_LO, int B_HI>
-__device__ __forceinline__ void ntt_load_roots(uint2 (&r)[15], const uint32_t *__restrict__ RW, int t)
-{
-    constexpr int N = 1 << LOGN;
-    // top window: t < n/16 = 2^C, so t >> C == 0 and the root indices are compile-time constants
-    const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
-    static_for<B_LO, B_HI>([&](auto bc) {
-        constexpr int b      = decltype(bc)::value;
-        constexpr int h      = N >> (C + b + 1);
-        constexpr int groups = 1 << (3 - b);
-        static_for<0, groups>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            const int idx   = h + ((thi << (3 - b)) | g);
-#ifdef SEAMD_ABL_NO_ROOT_LOADS
-            r[groups - 1 + g] = make_uint2(12345u + idx, 54321u);
-#else
-            r[groups - 1 + g] = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
-#endif
-        });
-    });
-}
-
-template <int B_LO, int B_HI>
-__device__ __forceinline__ void ntt_pass_regs(uint32_t (&x)[16], const uint2 (&r)[15], uint32_t neg_q,
-                                              uint32_t two_q)
-{
-    static_for<0, B_HI - B_LO>([&](auto sc) {
-        constexpr int b      = B_HI - 1 - decltype(sc)::value;  // descending
-        constexpr int groups = 1 << (3 - b);
-        static_for<0, groups>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            const uint2 rw  = r[groups - 1 + g];
-            static_for<0, (1 << b)>([&](auto rc) {
-                constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
-                constexpr int e1 = e0 | (1 << b);
-                ct_butterfly(x[e0], x[e1], rw.x, rw.y, neg_q, two_q);
-            });
-        });
-    });
-}
-
-// The same pass with the root loads at their points of use (lowest register pressure inside the
-// pass; used for the top window, whose roots are scalar loads, and where prefetching would spill).
 template <int LOGN, int C, int B_LO, int B_HI>
 __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
                                          uint32_t neg_q, uint32_t two_q, int t)
@@ -257,28 +209,86 @@ __device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__r
     }
 }
 
-// The same transform with the roots of each lower pass requested BEFORE the LDS exchange that
-// precedes it (they differ per lane there, so they are vector loads from the L2-resident table;
-// costs up to 30 VGPRs across the exchange -- callers with registers to spare only).  n <= 4096.
-template <int LOGN>
-__device__ __forceinline__ void ntt_tiles_prefetch(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
-                                                   uint32_t q, uint32_t *lds, int t)
+// ------------------------------------------------------------------------------------------
+// Three forward NTTs mod the same prime at once (the public-key path: u_hat, NTT(e1), NTT(m+e0),
+// ckks_asym.c:235-284).  Every root pair is loaded once for three butterflies, the three point sets
+// cross LDS through three planes under ONE barrier pair per exchange, and the three independent
+// butterfly streams give the two-waves-per-SIMD kernel the ILP it lacks (7.16 -> 6.71 ms per 65 536 at
+// n = 4096; requesting the roots before the exchange on top of this was slower, 6.95 ms).
+// ------------------------------------------------------------------------------------------
+template <int LOGN, int C_FROM, int C_TO>
+__device__ __forceinline__ void redeal3(uint32_t (&a)[16], uint32_t (&b)[16], uint32_t (&c)[16],
+                                        uint32_t *lds, int t)
 {
-    static_assert(LOGN <= 12, "three-pass form only");
+    constexpr int SL = XformGeom<LOGN>::SLOTS;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const int s = lds_slot(tile_index<C_FROM>(t, e));
+        lds[s] = a[e], lds[SL + s] = b[e], lds[2 * SL + s] = c[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const int s = lds_slot(tile_index<C_TO>(t, e));
+        a[e] = lds[s], b[e] = lds[SL + s], c[e] = lds[2 * SL + s];
+    }
+    __syncthreads();
+}
+
+template <int LOGN, int C, int B_LO, int B_HI>
+__device__ __forceinline__ void ntt_pass3(uint32_t (&x)[16], uint32_t (&y)[16], uint32_t (&z)[16],
+                                          const uint32_t *__restrict__ RW, uint32_t neg_q,
+                                          uint32_t two_q, int t)
+{
+    constexpr int N = 1 << LOGN;
+    const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
+    static_for<0, B_HI - B_LO>([&](auto sc) {
+        constexpr int b      = B_HI - 1 - decltype(sc)::value;  // descending
+        constexpr int h      = N >> (C + b + 1);
+        constexpr int groups = 1 << (3 - b);
+        static_for<0, groups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int idx   = h + ((thi << (3 - b)) | g);
+            const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
+            static_for<0, (1 << b)>([&](auto rc) {
+                constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
+                constexpr int e1 = e0 | (1 << b);
+                ct_butterfly(x[e0], x[e1], rw.x, rw.y, neg_q, two_q);
+                ct_butterfly(y[e0], y[e1], rw.x, rw.y, neg_q, two_q);
+                ct_butterfly(z[e0], z[e1], rw.x, rw.y, neg_q, two_q);
+            });
+        });
+    });
+}
+
+template <int LOGN>
+__device__ __forceinline__ void ntt_tiles3(uint32_t (&x)[16], uint32_t (&y)[16], uint32_t (&z)[16],
+                                           const uint32_t *__restrict__ RW, uint32_t q, uint32_t *lds,
+                                           int t)
+{
     using G              = XformGeom<LOGN>;
     const uint32_t two_q = q << 1;
     const uint32_t neg_q = 0u - q;
     constexpr int C0     = LOGN - 4;
-    constexpr int C1     = G::ntt_c(1);  // LOGN - 8
-    ntt_pass<LOGN, C0, 0, 4>(x, RW, neg_q, two_q, t);  // top window: scalar root loads
-    uint2 r1[15];
-    ntt_load_roots<LOGN, C1, 0, 4>(r1, RW, t);
-    redeal<C0, C1>(x, lds, t);
-    ntt_pass_regs<0, 4>(x, r1, neg_q, two_q);
-    uint2 r2[15];
-    ntt_load_roots<LOGN, 0, 0, C1>(r2, RW, t);
-    redeal<C1, 0>(x, lds, t);
-    ntt_pass_regs<0, C1>(x, r2, neg_q, two_q);  // remaining bits C1-1 .. 0
+    constexpr int C1     = G::ntt_c(1);
+    ntt_pass3<LOGN, C0, 0, 4>(x, y, z, RW, neg_q, two_q, t);
+    redeal3<LOGN, C0, C1>(x, y, z, lds, t);
+    ntt_pass3<LOGN, C1, 0, 4>(x, y, z, RW, neg_q, two_q, t);
+    if constexpr (LOGN <= 12)
+    {
+        redeal3<LOGN, C1, 0>(x, y, z, lds, t);
+        ntt_pass3<LOGN, 0, 0, C1>(x, y, z, RW, neg_q, two_q, t);
+    }
+    else
+    {
+        constexpr int C2 = G::ntt_c(2);
+        redeal3<LOGN, C1, C2>(x, y, z, lds, t);
+        ntt_pass3<LOGN, C2, 0, 4>(x, y, z, RW, neg_q, two_q, t);
+        redeal3<LOGN, C2, 0>(x, y, z, lds, t);
+        ntt_pass3<LOGN, 0, 0, C2>(x, y, z, RW, neg_q, two_q, t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
