@@ -212,7 +212,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 store16(A.c0 + off, out);
             }
         }
-        else         if constexpr (MODE == kModeAsym)
+        else if constexpr (MODE == kModeAsym)
         {
             // u_hat = NTT(expand(u))   (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1)
             uint32_t uh[16];
