@@ -179,6 +179,7 @@ def main():
 
     n, npr, mode, defB, bytes_per_unit = WORKLOADS[args.workload]
     B = args.batch or defB
+    ge.ensure_built()
     pkg = ge.load_package()
     ctx = pkg.Context(n, npr, local_rank)
     sk = V.secret_key(n)
