@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU): random parameter sets, batch sizes, seeds, value distributions,
+pipeline shapes and host-chunk sizes, every ciphertext compared bit for bit with the CPU oracle.
+Runs for FUZZ_SECONDS (default 150).  Not part of the test suite; a failure prints the seed."""
+import os, sys, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import vectors as V
+import __graft_entry__ as ge
+from oracle.pyoracle import Oracle
+pkg = ge.load_package()
+dev = torch.device("cuda:0")
+budget = float(os.environ.get("FUZZ_SECONDS", "150"))
+master = int(os.environ.get("FUZZ_SEED", str(int(time.time()))))
+print("fuzz master seed", master, flush=True)
+rng = random.Random(master)
+SHAPES = [(1024, 1), (2048, 1), (4096, 1), (4096, 2), (4096, 3), (8192, 2), (8192, 6), (16384, 3), (16384, 6)]
+t0 = time.time(); cases = cts = 0
+ctxs = {}
+def T(a): return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+while time.time() - t0 < budget:
+    n, npr = rng.choice(SHAPES)
+    big = n >= 8192
+    B = rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 257, 300] if not big else [1, 2, 5, 33, 64, 65, 70])
+    mode = rng.choice(["sym", "sym", "asym", "host", "hostasym"])
+    case_seed = rng.getrandbits(32)
+    nr = np.random.default_rng(case_seed)
+    key = (n, npr)
+    if key not in ctxs:
+        ctx = pkg.Context(n, npr); sk = V.secret_key(n, seed=n + npr); ctx.set_secret_key(sk)
+        o = Oracle(n, npr)
+        pk0, pk1 = o.gen_pk(sk, bytes(range(64)), bytes(range(1, 65)))
+        ctx.set_public_key(pk0, pk1)
+        ctxs[key] = (ctx, o, sk, pk0, pk1)
+    ctx, o, sk, pk0, pk1 = ctxs[key]
+    kind = rng.randrange(4)
+    if kind == 0:
+        vals = V.bench_values(B, n, seed=case_seed)
+    elif kind == 1:
+        vals = (nr.standard_normal((B, n // 2)) * 3).astype(np.float32)
+    elif kind == 2:
+        vals = np.zeros((B, n // 2), dtype=np.float32); vals[:, nr.integers(0, n // 2)] = 1
+    else:
+        vals = nr.uniform(-30, 30, (B, n // 2)).astype(np.float32)
+    ss = nr.integers(0, 256, (B, 64), dtype=np.uint8); sd = nr.integers(0, 256, (B, 64), dtype=np.uint8)
+    ov, sp = rng.choice([(1, 2), (1, 2), (0, 0), (1, 0), (0, 1), (1, 1)])
+    ctx.set_pipeline(ov, sp)
+    ctx.set_reject_list_capacity(rng.choice([0, 0, 0, 3, 40]) or max(256, n // 16))
+    desc = f"seed={master} case={cases} n={n} np={npr} B={B} mode={mode} vals={kind} pipe=({ov},{sp}) case_seed={case_seed}"
+    if mode in ("sym", "asym"):
+        c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.zeros_like(c0)
+        st = torch.zeros(B, dtype=torch.uint8, device=dev)
+        if mode == "sym": ctx.encrypt_sym(T(vals), T(ss), T(sd), c0, c1, status=st)
+        else: ctx.encrypt_asym(T(vals), T(sd), c0, c1, status=st)
+        torch.cuda.synchronize()
+        g0, g1, gs = c0.cpu().numpy().view(np.uint32), c1.cpu().numpy().view(np.uint32), st.cpu().numpy()
+    else:
+        ctx.set_host_chunk(rng.choice([0, 0, 1, 7, 64, 100]))
+        r = ctx.encrypt_sym_host(vals, ss, sd) if mode == "host" else ctx.encrypt_asym_host(vals, sd)
+        g0, g1, gs = r["c0"], r["c1"], r["status"]
+        ctx.set_host_chunk(0)
+    check = range(B) if B <= 70 else sorted(set([0, 1, 62, 63, 64, 65, B - 2, B - 1] + [rng.randrange(B) for _ in range(24)]))
+    for b in check:
+        e = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk) if mode in ("sym", "host") else \
+            o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+        if not (e["ok"] == bool(gs[b]) and (not e["ok"] or ((g0[b] == e["c0"]).all() and (g1[b] == e["c1"]).all()))):
+            print("MISMATCH", desc, "ct", b, flush=True); sys.exit(1)
+        cts += 1
+    cases += 1
+    if cases % 20 == 0: print(f"{cases} cases, {cts} ciphertexts checked, {time.time()-t0:.0f}s", flush=True)
+print(f"fuzz ok: {cases} cases, {cts} ciphertexts bit-exact in {time.time()-t0:.0f}s (master seed {master})")
