@@ -263,6 +263,15 @@ int se_amd_stage_ms(se_amd_ctx *ctx, float *ms /*[SE_AMD_STAGE_COUNT]*/,
                     uint64_t *launches /*[SE_AMD_STAGE_COUNT]*/, int reset);
 /* test hook: capacity of the per-ciphertext rejection list of the uniform sampler (default 256);
  * tiny values force the overflow path. */
+/* Host-only (no device needed): the setup-time tables the context uploads, for inspection and for
+ * CPU-side checks.  Any output pointer may be NULL.  q[np]; const_ratio[np][2] = floor(2^64/q) as
+ * {lo, hi} (modulus.c:30-47); index_map[n] (ckks_common.c:32-68); ifft_w[n][2] = (cos, -sin) of
+ * 2*pi*bitrev(t)/2n from the host libm (fft.c:39-45); ntt_rw / intt_rw [np][n][2] = (root,
+ * floor(root*2^32/q)) with root[bitrev(i)] = psi^i resp. psi^-i (ntt.c:40-52, intt.c:26-58).
+ * Returns SE_SUCCESS or SE_ERR_INVALD_ARGUMENT for an unsupported (degree, nprimes). */
+int se_amd_host_tables(size_t degree, size_t nprimes, uint32_t *q, uint32_t *const_ratio,
+                       double *scale, uint16_t *index_map, double *ifft_w, uint32_t *ntt_rw,
+                       uint32_t *intt_rw);
 int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
 /* test hook: redraw candidates the helper waves precompute per ciphertext (default n/32); tiny
  * values force the pooled fallback for the remaining draws. */

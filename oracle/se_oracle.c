@@ -298,8 +298,14 @@ void seo_ifft_twiddles(size_t n, size_t logn, double *w)
     {
         size_t k     = seo_bitrev(t, logn) & (m - 1);
         double angle = 2 * M_PI * (double)k / (double)(m);
-        w[2 * t]     = cos(angle);
-        w[2 * t + 1] = -sin(angle);
+        /* The reference writes cos(angle), sin(angle) (fft.c:43-44); its Release build (gcc -O3)
+         * fuses them into one glibc sincos() call, whose results differ from sin()/cos() by 1 ulp
+         * at a few angles.  The golden vectors come from that build, so sincos is explicit here
+         * (independent of this file's optimisation level). */
+        double sn, cs;
+        sincos(angle, &sn, &cs);
+        w[2 * t]     = cs;
+        w[2 * t + 1] = -sn;
     }
 }
 

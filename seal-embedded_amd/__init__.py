@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_pack_ternary_host", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
     "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
-    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -114,6 +114,7 @@ def lib():
     L.se_amd_set_reject_list_capacity.argtypes = [vp, u32]
     L.se_amd_set_speculation_capacity.argtypes = [vp, u32]
     L.se_amd_set_host_chunk.argtypes = [vp, sz]
+    L.se_amd_host_tables.argtypes = [sz, sz, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_reserve.argtypes = [vp, sz]
     L.se_amd_set_debug_flags.argtypes = [vp, u32]
     L.se_amd_set_pipeline.argtypes = [vp, i32, i32]
@@ -141,6 +142,19 @@ def _ptr(t):
 def _stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_tables(n, nprimes):
+    """Setup-time tables computed on the host (no GPU needed): dict of numpy arrays."""
+    import numpy as np
+    L = lib()
+    q = np.zeros(nprimes, np.uint32); cr = np.zeros((nprimes, 2), np.uint32)
+    scale = C.c_double(0)
+    imap = np.zeros(n, np.uint16); w = np.zeros((n, 2), np.float64)
+    rw = np.zeros((nprimes, n, 2), np.uint32); irw = np.zeros_like(rw)
+    _check(L.se_amd_host_tables(n, nprimes, _ptr(q), _ptr(cr), C.c_void_p(C.addressof(scale)), _ptr(imap), _ptr(w),
+                                _ptr(rw), _ptr(irw)), "se_amd_host_tables")
+    return dict(q=q, const_ratio=cr, scale=scale.value, index_map=imap, ifft_w=w, ntt_rw=rw, intt_rw=irw)
 
 
 class Context:

@@ -335,6 +335,52 @@ int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags)
     return SE_SUCCESS;
 }
 
+int se_amd_host_tables(size_t degree, size_t nprimes, uint32_t *q, uint32_t *const_ratio,
+                       double *scale, uint16_t *index_map, double *ifft_w, uint32_t *ntt_rw,
+                       uint32_t *intt_rw)
+{
+    seamd::HostParams hp;
+    if (seamd::host_params_init(hp, degree, nprimes) != 0)
+    {
+        seamd::set_last_error("unsupported parameter set (degree, nprimes)");
+        return SE_ERR_INVALD_ARGUMENT;
+    }
+    const size_t n = hp.n;
+    for (size_t j = 0; j < hp.nprimes; j++)
+    {
+        if (q) q[j] = hp.q[j];
+        if (const_ratio) const_ratio[2 * j] = hp.cr_lo[j], const_ratio[2 * j + 1] = hp.cr_hi[j];
+    }
+    if (scale) *scale = hp.scale;
+    if (index_map)
+    {
+        std::vector<uint16_t> map, inv;
+        seamd::host_index_map(hp, map, inv);
+        memcpy(index_map, map.data(), n * sizeof(uint16_t));
+    }
+    if (ifft_w)
+    {
+        std::vector<double> w;
+        seamd::host_ifft_twiddles(hp, w);
+        memcpy(ifft_w, w.data(), 2 * n * sizeof(double));
+    }
+    for (size_t j = 0; j < hp.nprimes; j++)
+    {
+        std::vector<uint32_t> rw;
+        if (ntt_rw)
+        {
+            seamd::host_ntt_root_pairs(hp, j, rw);
+            memcpy(ntt_rw + 2 * n * j, rw.data(), 2 * n * sizeof(uint32_t));
+        }
+        if (intt_rw)
+        {
+            seamd::host_intt_root_pairs(hp, j, rw);
+            memcpy(intt_rw + 2 * n * j, rw.data(), 2 * n * sizeof(uint32_t));
+        }
+    }
+    return SE_SUCCESS;
+}
+
 int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;

@@ -143,8 +143,14 @@ void host_ifft_twiddles(const HostParams &hp, std::vector<double> &w)
     {
         size_t k     = bitrev(t, hp.logn) & (m - 1);
         double angle = 2 * M_PI * (double)k / (double)(m);  // left-to-right, as fft.c:29
-        w[2 * t]     = cos(angle);
-        w[2 * t + 1] = -sin(angle);                          // conjugate (fft.c:129)
+        // fft.c:43-44 calls cos(angle) and sin(angle); gcc -O1+ (the reference's Release build, and
+        // the build the golden vectors come from) fuses the pair into ONE glibc sincos() call, and
+        // sincos() differs from sin()/cos() by 1 ulp at a few angles (2 of 8192 table entries at
+        // n = 4096, 23 at n = 16384).  clang does not fuse, so the call is explicit here.
+        double sn, cs;
+        sincos(angle, &sn, &cs);
+        w[2 * t]     = cs;
+        w[2 * t + 1] = -sn;                                  // conjugate (fft.c:129)
     }
 }
 

@@ -103,3 +103,41 @@ def test_examples_compile_as_plain_c(tmp_path):
         subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-c",
                         os.path.join(root, "examples", name + ".c"), "-I" + os.path.join(root, "include"),
                         "-o", str(tmp_path / (name + ".o"))], check=True)
+
+
+@pytest.mark.parametrize("shape", [(1024, 1), (2048, 1), (4096, 3), (8192, 6), (16384, 13)])
+def test_host_tables_match_oracle_and_golden(pkg, shape):
+    """The setup-time tables the context uploads (host logic, no GPU): parameter set, index map,
+    libm IFFT roots (bit-exact doubles; digest pinned to the reference build host), NTT
+    roots + Shoup companions, inverse roots."""
+    import hashlib
+    import json
+    import numpy as np
+    from oracle.pyoracle import Oracle
+    n, npr = shape
+    t = pkg.host_tables(n, npr)
+    o = Oracle(n, npr)
+    assert [int(x) for x in t["q"]] == [int(o.p.q[j]) for j in range(npr)]
+    assert [(int(a), int(b)) for a, b in t["const_ratio"]] == \
+        [(int(o.p.cr_lo[j]), int(o.p.cr_hi[j])) for j in range(npr)]
+    for j in range(npr):
+        q = int(t["q"][j])
+        cr = (int(t["const_ratio"][j][1]) << 32) | int(t["const_ratio"][j][0])
+        assert cr == (1 << 64) // q
+    assert t["scale"] == o.p.scale
+    assert (t["index_map"] == o.map).all()
+    tw = o.twiddles()
+    assert t["ifft_w"].ravel().tobytes() == tw.tobytes()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dig = json.load(open(os.path.join(root, "tests", "golden", "golden_digests.json")))["ifft_twiddle_sha256"]
+    assert hashlib.sha256(t["ifft_w"].astype("<f8").tobytes()).hexdigest() == dig[str(n)]
+    for j in range(npr):
+        q = int(t["q"][j])
+        r = t["ntt_rw"][j, :, 0].astype(np.uint64)
+        assert (r == o.ntt_roots(j)).all()
+        assert (t["ntt_rw"][j, :, 1].astype(np.uint64) == (r << np.uint64(32)) // np.uint64(q)).all()
+        ir = t["intt_rw"][j, :, 0].astype(np.uint64)
+        assert ((r * ir) % np.uint64(q) == 1).all()       # same bit-reversed slot: psi^i * psi^-i
+        assert (t["intt_rw"][j, :, 1].astype(np.uint64) == (ir << np.uint64(32)) // np.uint64(q)).all()
+    with pytest.raises(pkg.SealEmbeddedAmdError):
+        pkg.host_tables(3000, 1)
