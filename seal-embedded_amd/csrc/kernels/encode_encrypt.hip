@@ -466,7 +466,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_decrypt_decode(Dev
     const int t      = threadIdx.x;
     const size_t b   = blockIdx.x;
     const int j      = A.j;
-    const uint32_t q = P.q[j], two_q = q << 1;
+    const uint32_t q = P.q[j];
     const size_t rec = (b * A.in_primes + (A.in_primes > 1 ? j : 0)) * N + 16 * t;
 
     uint32_t x[16];
