@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_sample_cbd(CbdArgs A)
     uint64_t ctr = (A.ctr_base ? A.ctr_base[b] : 0) + k;
     KeccakState st;
     prng_absorb(st, seed, ctr);
-    keccak_f1600_fresh(st);  // only 96 of the 200 state bytes are consumed
+    keccak_f1600_fresh<true>(st);  // only 96 of the 200 state bytes are consumed (folded theta: keccak.cuh)
     uint32_t w[24];
 #pragma unroll
     for (int i = 0; i < 12; i++)
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(1024) void k_sample_ternary(TernaryArgs A)
     {
         KeccakState st;
         prng_absorb(st, seed, ctr);
-        keccak_f1600_fresh(st);  // a block uses 96 bytes, a redraw 1 byte
+        keccak_f1600_fresh<true>(st);  // a block uses 96 bytes, a redraw 1 byte
         if (!done)
         {
             ctr++;
