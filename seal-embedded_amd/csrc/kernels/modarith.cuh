@@ -51,16 +51,17 @@ __device__ __forceinline__ uint32_t reduce_signed(int64_t x, uint32_t q, uint32_
 }
 
 // Harvey butterfly, inputs/outputs in [0,4q): (X, Y) -> (X + Y*w, X - Y*w)  (ntt.c:156-162).
-// 8 VALU ops: mul_hi, mul_lo, mad_u64_u32 (y*w - h*q as h*(2^32-q) + y*w mod 2^32), sub, min,
-// add, add, sub.
-__device__ __forceinline__ void ct_butterfly(uint32_t &x, uint32_t &y, uint32_t w, uint32_t wp,
-                                             uint32_t neg_q, uint32_t two_q)
+// `nw` is the NEGATED root (2^32 - w) and `wp` its Shoup companion floor(w 2^32 / q), so that
+// tn = h*q + y*nw = -(y*w - h*q) = -t (mod 2^32) with t in [0,2q), and both outputs are single adds:
+// 7 VALU ops: sub+min (x into [0,2q)), mul_hi, mul_lo, mad_u64_u32, sub, add3.
+__device__ __forceinline__ void ct_butterfly(uint32_t &x, uint32_t &y, uint32_t nw, uint32_t wp,
+                                             uint32_t q, uint32_t two_q)
 {
-    uint32_t u = min(x, x - two_q);
-    uint32_t h = __umulhi(y, wp);
-    uint32_t t = (uint32_t)((uint64_t)h * (uint64_t)neg_q + (uint64_t)(y * w));  // [0,2q)
-    x          = u + t;
-    y          = (u + two_q) - t;
+    uint32_t u  = min(x, x - two_q);
+    uint32_t h  = __umulhi(y, wp);
+    uint32_t tn = (uint32_t)((uint64_t)h * (uint64_t)q + (uint64_t)(y * nw));  // -t mod 2^32
+    x           = u - tn;
+    y           = u + two_q + tn;
 }
 
 // 16 signed plaintext coefficients -> residues.  When every magnitude in the WAVE fits 32 bits

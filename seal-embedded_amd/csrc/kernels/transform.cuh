@@ -151,11 +151,11 @@ __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
 
 // ------------------------------------------------------------------------------------------
 // NTT pass: stages for local bits [B_LO, B_HI) of a tile at window C, descending.
-// RW = interleaved (root, shoup(root)) table of one prime.
+// RW = interleaved (-root mod 2^32, shoup(root)) table of one prime.
 // ------------------------------------------------------------------------------------------
 template <int LOGN, int C, int B_LO, int B_HI>
 __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
-                                         uint32_t neg_q, uint32_t two_q, int t)
+                                         uint32_t q, uint32_t two_q, int t)
 {
     constexpr int N = 1 << LOGN;
     const int thi   = (C + 4 >= LOGN) ? 0 : (t >> C);
@@ -174,7 +174,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
-                ct_butterfly(x[e0], x[e1], rw.x, rw.y, neg_q, two_q);
+                ct_butterfly(x[e0], x[e1], rw.x, rw.y, q, two_q);
             });
         });
     });
@@ -188,24 +188,23 @@ __device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__r
 {
     using G              = XformGeom<LOGN>;
     const uint32_t two_q = q << 1;
-    const uint32_t neg_q = 0u - q;
     constexpr int C0     = LOGN - 4;
-    ntt_pass<LOGN, C0, 0, 4>(x, RW, neg_q, two_q, t);
+    ntt_pass<LOGN, C0, 0, 4>(x, RW, q, two_q, t);
     constexpr int C1 = G::ntt_c(1);  // LOGN - 8
     redeal<C0, C1>(x, lds, t);
-    ntt_pass<LOGN, C1, 0, 4>(x, RW, neg_q, two_q, t);
+    ntt_pass<LOGN, C1, 0, 4>(x, RW, q, two_q, t);
     if constexpr (LOGN <= 12)
     {
         redeal<C1, 0>(x, lds, t);
-        ntt_pass<LOGN, 0, 0, C1>(x, RW, neg_q, two_q, t);  // remaining bits C1-1 .. 0
+        ntt_pass<LOGN, 0, 0, C1>(x, RW, q, two_q, t);  // remaining bits C1-1 .. 0
     }
     else
     {
         constexpr int C2 = G::ntt_c(2);  // LOGN - 12 (1 or 2)
         redeal<C1, C2>(x, lds, t);
-        ntt_pass<LOGN, C2, 0, 4>(x, RW, neg_q, two_q, t);
+        ntt_pass<LOGN, C2, 0, 4>(x, RW, q, two_q, t);
         redeal<C2, 0>(x, lds, t);
-        ntt_pass<LOGN, 0, 0, C2>(x, RW, neg_q, two_q, t);
+        ntt_pass<LOGN, 0, 0, C2>(x, RW, q, two_q, t);
     }
 }
 
@@ -239,7 +238,7 @@ __device__ __forceinline__ void redeal3(uint32_t (&a)[16], uint32_t (&b)[16], ui
 
 template <int LOGN, int C, int B_LO, int B_HI>
 __device__ __forceinline__ void ntt_pass3(uint32_t (&x)[16], uint32_t (&y)[16], uint32_t (&z)[16],
-                                          const uint32_t *__restrict__ RW, uint32_t neg_q,
+                                          const uint32_t *__restrict__ RW, uint32_t q,
                                           uint32_t two_q, int t)
 {
     constexpr int N = 1 << LOGN;
@@ -255,9 +254,9 @@ __device__ __forceinline__ void ntt_pass3(uint32_t (&x)[16], uint32_t (&y)[16], 
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
-                ct_butterfly(x[e0], x[e1], rw.x, rw.y, neg_q, two_q);
-                ct_butterfly(y[e0], y[e1], rw.x, rw.y, neg_q, two_q);
-                ct_butterfly(z[e0], z[e1], rw.x, rw.y, neg_q, two_q);
+                ct_butterfly(x[e0], x[e1], rw.x, rw.y, q, two_q);
+                ct_butterfly(y[e0], y[e1], rw.x, rw.y, q, two_q);
+                ct_butterfly(z[e0], z[e1], rw.x, rw.y, q, two_q);
             });
         });
     });
@@ -270,24 +269,23 @@ __device__ __forceinline__ void ntt_tiles3(uint32_t (&x)[16], uint32_t (&y)[16],
 {
     using G              = XformGeom<LOGN>;
     const uint32_t two_q = q << 1;
-    const uint32_t neg_q = 0u - q;
     constexpr int C0     = LOGN - 4;
     constexpr int C1     = G::ntt_c(1);
-    ntt_pass3<LOGN, C0, 0, 4>(x, y, z, RW, neg_q, two_q, t);
+    ntt_pass3<LOGN, C0, 0, 4>(x, y, z, RW, q, two_q, t);
     redeal3<LOGN, C0, C1>(x, y, z, lds, t);
-    ntt_pass3<LOGN, C1, 0, 4>(x, y, z, RW, neg_q, two_q, t);
+    ntt_pass3<LOGN, C1, 0, 4>(x, y, z, RW, q, two_q, t);
     if constexpr (LOGN <= 12)
     {
         redeal3<LOGN, C1, 0>(x, y, z, lds, t);
-        ntt_pass3<LOGN, 0, 0, C1>(x, y, z, RW, neg_q, two_q, t);
+        ntt_pass3<LOGN, 0, 0, C1>(x, y, z, RW, q, two_q, t);
     }
     else
     {
         constexpr int C2 = G::ntt_c(2);
         redeal3<LOGN, C1, C2>(x, y, z, lds, t);
-        ntt_pass3<LOGN, C2, 0, 4>(x, y, z, RW, neg_q, two_q, t);
+        ntt_pass3<LOGN, C2, 0, 4>(x, y, z, RW, q, two_q, t);
         redeal3<LOGN, C2, 0>(x, y, z, lds, t);
-        ntt_pass3<LOGN, 0, 0, C2>(x, y, z, RW, neg_q, two_q, t);
+        ntt_pass3<LOGN, 0, 0, C2>(x, y, z, RW, q, two_q, t);
     }
 }
 

@@ -83,6 +83,9 @@ int Context::init(size_t n, size_t nprimes, int dev)
     for (size_t j = 0; j < nprimes; j++)
     {
         host_ntt_root_pairs(hp, j, rw);
+        // the device table holds (-root mod 2^32, shoup(root)): the forward butterfly then needs no
+        // separate negation (ct_butterfly, modarith.cuh)
+        for (size_t i = 0; i < n; i++) rw[2 * i] = 0u - rw[2 * i];
         memcpy(rw_all.data() + 2 * n * j, rw.data(), 2 * n * sizeof(uint32_t));
     }
     SEAMD_HIP(hipMalloc((void **)&d_inv_map, n * sizeof(uint16_t)));

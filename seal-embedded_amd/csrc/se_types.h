@@ -30,7 +30,7 @@ struct DevTables
 {
     const uint16_t *inv_map;   // [n]   x[k] <- values[inv_map[k] & (n/2-1)]
     const double *ifft_w;      // [n][2] (re, im) of W[t], t = h + j  (fft.c:129)
-    const uint32_t *ntt_rw;    // [np][n][2] (root, shoup(root)) indexed h + g (ntt.c:40-52)
+    const uint32_t *ntt_rw;    // [np][n][2] (-root mod 2^32, shoup(root)) indexed h + g (ntt.c:40-52)
     const uint32_t *s_hat;     // [np][n][2] (NTT(s), shoup)       sym
     const uint32_t *pk0;       // [np][n][2] (pk0, shoup)          asym
     const uint32_t *pk1;       // [np][n][2] (pk1, shoup)          asym
