@@ -71,7 +71,7 @@ __device__ __forceinline__ void load16_pairs(uint32_t (&w)[16], uint32_t (&wp)[1
 template <int LOGN>
 __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTables &T,
                                                  const float *values, uint8_t *status, size_t b,
-                                                 unsigned char *smem, int64_t (&m)[16])
+                                                 unsigned char *smem, int64_t (&m)[16], bool &small)
 {
     using G          = XformGeom<LOGN>;
     constexpr int N  = G::N;
@@ -107,17 +107,32 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     // inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183)
     ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
 
-    // round to int64, overflow check (ckks_common.c:183-206)
-    int ok = 1;
+    // round to int64, overflow check (ckks_common.c:183-206).  The largest magnitude of the thread
+    // serves both the overflow test and the wave-uniform "small" flag: when every coefficient of
+    // the wave stays below 2^31 - 64 (the normal case, |m| ~ scale * |value|; the margin covers the
+    // error term added later, |e| <= 21) the int64 conversion is one v_cvt_i32_f64 plus a sign
+    // extension, and the per-prime reduction can work on 32-bit magnitudes without re-checking.
+    double amax = 0.0;
 #pragma unroll
     for (int e = 0; e < 16; e++)
     {
-        double c = round(__dmul_rn(re[e], P.n_inv));
-        if (fabs(c) > 9223372036854775808.0) ok = 0;
-        m[e] = (int64_t)c;
+        re[e] = round(__dmul_rn(re[e], P.n_inv));
+        amax  = fmax(amax, fabs(re[e]));
     }
-    ok = __syncthreads_and(ok);
-    if (status && t == 0) status[b] = (uint8_t)ok;
+    const int ok = !(amax > 9223372036854775808.0);
+    small        = __all(amax < 2147483584.0);
+    if (small)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) m[e] = (int64_t)(int32_t)re[e];
+    }
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) m[e] = (int64_t)re[e];
+    }
+    const int all_ok = __syncthreads_and(ok);
+    if (status && t == 0) status[b] = (uint8_t)all_ok;
 }
 
 template <int LOGN, int MODE>
@@ -136,7 +151,8 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
     const int np   = P.nprimes;
 
     int64_t m[16];
-    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m);
+    bool small;  // wave-uniform: every |m + e| of this wave fits 31 bits
+    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
 
     // thread t now owns points k = t + (n/16)*e
     if constexpr (MODE == kModeSym)
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 int32_t e1    = A.err[b * 2 * N + N + (e << CTOP) + t];
                 y[e]          = (e1 < 0 ? q : 0u) + (uint32_t)e1;
             }
-            reduce_signed16(m, x, q, crh, crl);
+            reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
             {
                 // c1 = pk1 . u_hat + NTT(e1)   (:251)
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 store16(A.c1 + off, out);
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
-            reduce_signed16(m, x, q, crh, crl);
+            reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         else
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
-            reduce_signed16(m, x, q, crh, crl);
+            reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -311,7 +327,8 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
     const int np   = P.nprimes;
 
     int64_t m[16];
-    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m);
+    bool small;  // wave-uniform: every |m + e| of this wave fits 31 bits
+    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
     if constexpr (ADD_ERR)
     {
 #pragma unroll
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
     for (int j = 0; j < np; j++)
     {
         uint32_t x[16];
-        reduce_signed16(m, x, P.q[j], P.cr_hi[j], P.cr_lo[j]);
+        reduce_signed16(m, x, P.q[j], P.cr_hi[j], P.cr_lo[j], small);
         uint32_t *dst = A.c0 + (b * np + j) * N;
 #pragma unroll
         for (int e = 0; e < 16; e++) dst[(e << CTOP) + t] = x[e];

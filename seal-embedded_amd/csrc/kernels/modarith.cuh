@@ -64,27 +64,21 @@ __device__ __forceinline__ void ct_butterfly(uint32_t &x, uint32_t &y, uint32_t 
     y           = u + two_q + tn;
 }
 
-// 16 signed plaintext coefficients -> residues.  When every magnitude in the WAVE fits 32 bits
-// (the normal case: |m| ~ scale * |value|) the 64-bit Barrett collapses to the one-multiply
-// 32-bit form; otherwise all lanes take the general path.  Both give x mod q exactly.
+// 16 signed plaintext coefficients -> residues.  `small` (wave-uniform, from the encoder) says that
+// every magnitude in the WAVE fits 31 bits (the normal case: |m| ~ scale * |value|): the 64-bit
+// Barrett then collapses to the one-multiply 32-bit form on the low words; otherwise all lanes take
+// the general path.  Both give x mod q exactly (incl. the non-canonical q for negative multiples).
 __device__ __forceinline__ void reduce_signed16(const int64_t (&m)[16], uint32_t (&x)[16], uint32_t q,
-                                                uint32_t cr_hi, uint32_t cr_lo)
+                                                uint32_t cr_hi, uint32_t cr_lo, bool small)
 {
-    uint32_t any_hi = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++)
-    {
-        uint64_t mag = m[e] < 0 ? (uint64_t)0 - (uint64_t)m[e] : (uint64_t)m[e];
-        any_hi |= (uint32_t)(mag >> 32);
-    }
-    if (__all(any_hi == 0))
+    if (small)
     {
 #pragma unroll
         for (int e = 0; e < 16; e++)
         {
-            uint32_t lo  = (uint32_t)m[e];
-            bool neg     = m[e] < 0;
-            uint32_t mag = neg ? 0u - lo : lo;
+            int32_t v    = (int32_t)m[e];
+            bool neg     = v < 0;
+            uint32_t mag = neg ? 0u - (uint32_t)v : (uint32_t)v;
             uint32_t r   = barrett32(mag, q, cr_hi);
             x[e]         = neg ? q - r : r;
         }

@@ -573,6 +573,63 @@ def test_encode_only_config5(env):
             assert (got[b, j] == o.ntt(o.reduce_pte(m, j), j)).all()
 
 
+@pytest.mark.parametrize("n,npr", [(4096, 3), (1024, 1)])
+def test_magnitude_classes_through_every_path(env, n, npr):
+    """The encoder has a wave-uniform fast path for coefficients below 2^31 - 64 (one-instruction
+    int conversion, 32-bit reduction) and a general int64 path.  Plaintexts whose coefficients sit
+    well below, just around (2^31 -/+ a few) and far above that boundary go through encode-only,
+    symmetric and public-key encryption and must match the oracle (values chosen per row, so
+    different waves/workgroups take different paths in one launch)."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    o = Oracle(n, npr)
+    scale = o.p.scale
+    rng = np.random.default_rng(1234 + n)
+    rows = []
+    for amp in (1e-3, 1.0, 30.0, 2.0 ** 31 / scale * 0.999, 2.0 ** 31 / scale * 1.001, 1e3, 1e6, 1e9):
+        rows.append((rng.uniform(-1, 1, n // 2) * amp).astype(np.float32))
+        one = np.zeros(n // 2, dtype=np.float32)
+        one[int(rng.integers(0, n // 2))] = amp * n / 2       # a single large slot: flat coefficients ~ amp
+        rows.append(one)
+    vals = np.stack(rows)
+    B = vals.shape[0]
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=9)
+    ctx.set_secret_key(sk)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    ss, sd = V.bench_seeds(B, first=4242)
+    out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    pte = torch.zeros((B, n), dtype=torch.int64, device=env["dev"])
+    st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encode_ntt(dev_t(env, vals), out, pte=pte, status=st)
+    torch.cuda.synchronize()
+    g, gp, gs = host_u32(out), pte.cpu().numpy(), st.cpu().numpy()
+    kinds = set()
+    for b in range(B):
+        ok, m = o.encode(vals[b])
+        assert bool(gs[b]) == ok, b
+        if not ok:
+            continue
+        kinds.add(bool(np.abs(m).max() < 2 ** 31 - 64))
+        assert (gp[b] == m).all(), b
+        for j in range(npr):
+            assert (g[b, j] == o.ntt(o.reduce_pte(m, j), j)).all(), (b, j)
+    assert kinds == {True, False}
+    for split in (0, 1):
+        ctx.set_pipeline(1, split)
+        r = ctx.encrypt_sym_host(vals, ss, sd, want_extra=True)
+        ra = ctx.encrypt_asym_host(vals, sd, want_extra=True)
+        for b in range(B):
+            e = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+            ea = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+            assert bool(r["status"][b]) == e["ok"] and bool(ra["status"][b]) == ea["ok"]
+            if e["ok"]:
+                assert (r["c0"][b] == e["c0"]).all() and (r["c1"][b] == e["c1"]).all(), (split, b)
+                assert (r["pte"][b] == e["pte"]).all()
+                assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all(), (split, b)
+
+
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 129])
 def test_ragged_batch_sizes(env, B):
     from oracle.pyoracle import Oracle
