@@ -33,8 +33,8 @@ struct UniformArgs
     uint32_t *spec;        // [B][spec_cap] scratch: candidates precomputed by helper waves
     uint32_t spec_cap;
     uint32_t master_waves; // waves of a workgroup that own ciphertexts (the rest are redraw helpers)
-    uint32_t debug_flags;  // ablation (timing experiments only): 1 = no bulk stores, 2 = no phase 2,
-                           // 4 = no reject bookkeeping; 8 = no helper waves (results stay correct)
+    uint32_t debug_flags;  // ablation (timing experiments only): 2 = no phase 2 (wrong results);
+                           // 8 = no helper waves, 16 = helpers without speculation (results stay correct)
     uint32_t helper_fill;  // waves per workgroup that small batches are filled up to with helpers
                            // (0 = default 8 = two per SIMD; 4 leaves room for a co-resident
                            // 1024-thread transform workgroup at n = 16384)

@@ -138,44 +138,67 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
             KeccakState st;
             prng_absorb(st, seed, bulk_ctr);
 
-            // reject test and reduction of one word: sample.c:50-56
-            auto word = [&](uint32_t x, uint32_t idx) -> uint32_t {
-                uint32_t r = barrett32(x, q, crh);
-                if (x >= bound && !(A.debug_flags & 4))
+            // Reject test and reduction of one word (sample.c:50-56), branch-free: a lone wave per
+            // SIMD pays an issue slot for EVERY instruction, scalar and branch ones included, and
+            // with 64 lanes some lane rejects at ~70 % of the word positions, so a per-word
+            // `if (reject)` costs its mask/branch scaffolding 34 times per squeeze step.  Here each
+            // word is reduce + compare + select-marker + shift the reject bit into a per-lane
+            // mask; the masks are turned into reject-list entries once per step (a loop of
+            // max-over-lanes popcount, ~3 iterations).
+            auto word = [&](uint32_t x, uint32_t &mask) -> uint32_t {
+                const bool rej   = x >= bound;
+                const uint32_t r = barrett32(x, q, crh);
+                mask             = (mask << 1) | (rej ? 1u : 0u);
+                return rej ? kRejMarker : r;
+            };
+            // mask holds `count` words, word w of the step at bit (count - 1 - w); entries are
+            // appended in ascending position order
+            auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
+                while (__any(mask != 0))
                 {
-                    if (nrej < A.rej_cap) mylist[nrej] = idx;
-                    nrej++;
-                    r = kRejMarker;
+                    if (mask != 0)
+                    {
+                        const uint32_t p = (uint32_t)__clz((int)mask);
+                        mask &= ~(0x80000000u >> p);
+                        if (nrej < A.rej_cap) mylist[nrej] = first_pos + (p - (32u - count));
+                        nrej++;
+                    }
                 }
-                return r;
             };
 
             uint32_t idx = 0;
             for (int step = 0; step < FULL_STEPS; step++)
             {
                 keccak_f1600(st);
+                uint32_t m0 = 0, m1 = 0;  // words 0..31 / 32..33 of this step
 #pragma unroll
                 for (int i = 0; i < 17; i++)
                 {
-                    uint32_t w0 = word(st.lo[i], idx + 2 * i);
-                    uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
-                    if (!(A.debug_flags & 1))
-                        *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-                    else if (w0 == 0x12345678u && w1 == 0x9abcdef0u)
-                        mypoly[0] = w0;  // keeps the values live without storing them
+                    uint32_t &mk = (i < 16) ? m0 : m1;
+                    uint32_t w0  = word(st.lo[i], mk);
+                    uint32_t w1  = word(st.hi[i], mk);
+                    *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                }
+                if (__any((m0 | m1) != 0))
+                {
+                    flush(m0, 32, idx);
+                    flush(m1, 2, idx + 32);
                 }
                 idx += 34;
             }
             if constexpr (TAIL_WORDS > 0)
             {
+                static_assert(TAIL_WORDS <= 32 && TAIL_WORDS % 2 == 0, "tail fits one mask");
                 keccak_f1600(st);
+                uint32_t m0 = 0;
 #pragma unroll
                 for (int i = 0; i < TAIL_WORDS / 2; i++)
                 {
-                    uint32_t w0 = word(st.lo[i], idx + 2 * i);
-                    uint32_t w1 = word(st.hi[i], idx + 2 * i + 1);
+                    uint32_t w0 = word(st.lo[i], m0);
+                    uint32_t w1 = word(st.hi[i], m0);
                     *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
                 }
+                flush(m0, TAIL_WORDS, idx);
             }
         }
         // bulk stores (and list entries) must have landed before phase 2 patches / reads them
