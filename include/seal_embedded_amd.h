@@ -125,7 +125,8 @@ void se_cleanup(SE_PARMS *se_parms);
  * values [B][n/2] float; share_seeds [B][64] (ignored for asymmetric; may be NULL then);
  * seeds [B][64]; c0, c1 [B][np][n] uint32 out.  Symmetric only: c1 may be NULL -- seed-compressed
  * form, the receiver re-expands c1 = a from share_seeds (se_amd_expand_c1_device), which halves
- * the bytes crossing PCIe.  Returns SE_SUCCESS, or the number (>0) of
+ * the bytes crossing PCIe.  With $SE_AMD_DEVICES = "all" or a comma list at se_setup time the
+ * batch is sharded over those devices in contiguous blocks (one host thread per device).  Returns SE_SUCCESS, or the number (>0) of
  * plaintexts whose encoding overflowed int64 (their records are unspecified), or SE_ERR_*. */
 int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
                      const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1);

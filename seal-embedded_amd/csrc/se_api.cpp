@@ -10,6 +10,7 @@
 #include <sys/random.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/seal_embedded_amd.h"
@@ -474,6 +475,9 @@ static SE_PARMS g_se_parms;
 static std::vector<Modulus> g_moduli;
 static std::vector<uint8_t> g_pool;
 static se_amd_ctx *g_ctx = nullptr;
+// further contexts, one per additional device of $SE_AMD_DEVICES: se_encrypt_batch shards a batch
+// over all of them (contiguous blocks, one host thread and one PCIe link per device)
+static std::vector<se_amd_ctx *> g_more;
 
 static const char *data_path()
 {
@@ -494,20 +498,48 @@ SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals,
         se_amd_destroy(g_ctx);
         g_ctx = nullptr;
     }
-    int device     = getenv("SE_AMD_DEVICE") ? atoi(getenv("SE_AMD_DEVICE")) : 0;
-    int rc         = se_amd_create(&g_ctx, degree, nprimes, device);
-    if (rc != SE_SUCCESS)
+    for (se_amd_ctx *x : g_more) se_amd_destroy(x);
+    g_more.clear();
+    // devices: $SE_AMD_DEVICES = "all" or a comma list (batched entry shards over them); otherwise
+    // the single device $SE_AMD_DEVICE (default 0)
+    std::vector<int> devices;
+    if (const char *list = getenv("SE_AMD_DEVICES"))
     {
-        // error convention of the reference: print and exit (ckks_sym.c:68-72, fileops.c:60-91)
-        fprintf(stderr, "Error! se_setup failed: %s\n", se_amd_last_error());
-        exit(1);
+        if (strcmp(list, "all") == 0)
+        {
+            int count = 0;
+            if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+            for (int d = 0; d < count; d++) devices.push_back(d);
+        }
+        else
+        {
+            for (const char *p = list; *p;)
+            {
+                char *end;
+                long d = strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back((int)d);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
     }
+    if (devices.empty()) devices.push_back(getenv("SE_AMD_DEVICE") ? atoi(getenv("SE_AMD_DEVICE")) : 0);
     const bool asym = (encrypt_type == SE_ASYM_ENCR);
-    rc              = se_amd_load_keys_from_dir(g_ctx, data_path(), asym ? 1 : 0);
-    if (rc != SE_SUCCESS)
+    for (size_t i = 0; i < devices.size(); i++)
     {
-        fprintf(stderr, "Error! %s\n", se_amd_last_error());
-        exit(1);
+        se_amd_ctx *x = nullptr;
+        int rc        = se_amd_create(&x, degree, nprimes, devices[i]);
+        if (rc == SE_SUCCESS) rc = se_amd_load_keys_from_dir(x, data_path(), asym ? 1 : 0);
+        if (rc != SE_SUCCESS)
+        {
+            // error convention of the reference: print and exit (ckks_sym.c:68-72, fileops.c:60-91)
+            fprintf(stderr, "Error! se_setup failed: %s\n", se_amd_last_error());
+            exit(1);
+        }
+        if (i == 0)
+            g_ctx = x;
+        else
+            g_more.push_back(x);
     }
     const Context &c = g_ctx->c;
     const size_t n   = c.hp.n;
@@ -662,6 +694,8 @@ void se_cleanup(SE_PARMS *se_parms)
         se_amd_destroy(g_ctx);
         g_ctx = nullptr;
     }
+    for (se_amd_ctx *x : g_more) se_amd_destroy(x);
+    g_more.clear();
     g_pool.clear();
     g_moduli.clear();
     if (se_parms) se_parms->parms = 0;  // seal_embedded.c:234
@@ -671,10 +705,46 @@ int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
                      const uint8_t *share_seeds, const uint8_t *seeds, uint32_t *c0, uint32_t *c1)
 {
     if (!se_parms || !se_parms->parms || !g_ctx) return SE_ERR_INVALD_ARGUMENT;
-    if (se_parms->parms->is_asymmetric)
-        return se_amd_encrypt_asym_host(g_ctx, values, B, seeds, c0, c1, nullptr, nullptr, nullptr);
-    return se_amd_encrypt_sym_host(g_ctx, values, B, share_seeds, seeds, c0, c1, nullptr, nullptr,
-                                   nullptr);
+    const bool asym = se_parms->parms->is_asymmetric;
+    auto run        = [&](se_amd_ctx *ctx, size_t lo, size_t cnt) -> int {
+        const size_t n = ctx->c.hp.n, np = ctx->c.hp.nprimes;
+        uint32_t *o1   = c1 ? c1 + lo * np * n : nullptr;
+        if (asym)
+            return se_amd_encrypt_asym_host(ctx, values + lo * (n / 2), cnt, seeds + lo * 64,
+                                            c0 + lo * np * n, o1, nullptr, nullptr, nullptr);
+        return se_amd_encrypt_sym_host(ctx, values + lo * (n / 2), cnt,
+                                       share_seeds ? share_seeds + lo * 64 : nullptr, seeds + lo * 64,
+                                       c0 + lo * np * n, o1, nullptr, nullptr, nullptr);
+    };
+    const size_t ndev = 1 + g_more.size();
+    if (ndev == 1 || B < 2 * ndev) return run(g_ctx, 0, B);
+    if (!values || !seeds || !c0) return SE_ERR_INVALD_ARGUMENT;
+
+    // contiguous block per device, one host thread each (each drives its own PCIe link)
+    std::vector<int> rcs(ndev, 0);
+    std::vector<std::string> errs(ndev);
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < ndev; d++)
+    {
+        const size_t lo = B * d / ndev, hi = B * (d + 1) / ndev;
+        se_amd_ctx *ctx = d == 0 ? g_ctx : g_more[d - 1];
+        workers.emplace_back([&, d, lo, hi, ctx] {
+            rcs[d] = run(ctx, lo, hi - lo);
+            if (rcs[d] < 0) errs[d] = se_amd_last_error();  // thread-local: carry it to the caller
+        });
+    }
+    for (auto &w : workers) w.join();
+    int failed = 0;
+    for (size_t d = 0; d < ndev; d++)
+    {
+        if (rcs[d] < 0)
+        {
+            seamd::set_last_error(errs[d]);
+            return rcs[d];
+        }
+        failed += rcs[d];
+    }
+    return failed;
 }
 
 }  // extern "C"

@@ -823,16 +823,21 @@ def test_c_caller_of_reference_api_reproduces_reference_digest(env, golden, tmp_
     assert kv["fnv1a64"] == golden["digests"]["shapes"][f"{n}x{npr}"][f"api_fnv1a64_{mode}"]
 
 
-def test_c_caller_of_batch_entry(env, tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0"])
+def test_c_caller_of_batch_entry(env, tmp_path, devices):
     """examples/batch_encrypt.c: se_encrypt_batch from C with malloc'ed (pageable) buffers; the
-    records equal the oracle's per-ciphertext results in the reference's callback order."""
+    records equal the oracle's per-ciphertext results in the reference's callback order.  With
+    SE_AMD_DEVICES the batch is sharded over several contexts in one process (one host thread per
+    device; the same device listed repeatedly here, a single-GPU box, still exercises the split)."""
     import subprocess
     from oracle import pyoracle
     from oracle.pyoracle import Oracle
-    n, npr, B = 1024, 1, 5
+    n, npr, B = 1024, 1, 7
     exe = _build_example("batch_encrypt", tmp_path)
     data = _key_dir(env, tmp_path, n, npr, False)
     e = dict(os.environ, SE_AMD_DATA_PATH=str(data))
+    if devices:
+        e["SE_AMD_DEVICES"] = devices
     out = subprocess.run([str(exe), str(n), str(npr), str(B)], env=e, check=True, capture_output=True,
                          text=True, timeout=300).stdout
     kv = dict(f.split("=") for f in [l for l in out.splitlines() if l.startswith("failed=")][-1].split())
