@@ -44,14 +44,19 @@ __device__ __forceinline__ void load_seed(uint32_t (&seed)[16], const uint8_t *s
 //
 // Phase 1 (bulk block): 4n bytes are squeezed 136 at a time; each 32-bit word is reduced mod q
 // in registers (or replaced by a marker when it fails the rejection bound) and stored straight
-// to the lane's own polynomial as 8-byte pieces.  64 lanes write 64 different polynomials, so a
+// to the lane's own polynomial (16-byte pieces).  64 lanes write 64 different polynomials, so a
 // store instruction touches 64 lines -- but every lane completes a 128-byte line within about
 // one permutation, the partially written lines sit in L2 (64 x 128 B per wave) and reach HBM
 // as full lines.  (A cooperative LDS-transposed store was measured slower: +3x on the bulk step.)
+// The emit is branch-free (one wave per SIMD pays an issue slot for every scalar/branch
+// instruction): reject bits go into per-lane masks that become reject-list entries once per step.
 // Phase 2 (redraws): the k-th rejected coefficient takes the k-th accepted candidate of the
-// stream block(ctr+1)[0:4], block(ctr+2)[0:4], ...; all lanes draw in lock step until every
-// lane of the wave is done.  Rejected positions live in a per-ciphertext list in HBM scratch
-// (rej_cap entries); beyond that the lane rescans its own output for the marker word.
+// stream block(ctr+1)[0:4], block(ctr+2)[0:4], ...  Candidates are independent SHAKE calls, so the
+// phase is balanced: over the wave (lane slots dealt round-robin to the lanes that still need
+// draws), over the workgroup when helper waves are present (small batches), and with helper waves
+// precomputing candidates while the chains squeeze.  Rejected positions live in a per-ciphertext
+// list in HBM scratch (rej_cap entries); beyond that the lane rescans its own output for the
+// marker word.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid residue
 

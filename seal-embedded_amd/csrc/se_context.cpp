@@ -1,8 +1,11 @@
 // se_context.cpp -- GPU context: table upload, key preparation, scratch, and the kernel chains of
 // the whole-path entry points.
 //
-// Kernel chains (all on the caller's stream, no host synchronisation inside):
-//   symmetric  (ckks_sym.c:181-301):  k_sample_cbd -> k_sample_uniform(a -> c1) -> k_encode_encrypt
+// Kernel chains (no host synchronisation inside; an auxiliary stream of the context runs the kernels
+// that do not depend on each other side by side and is joined back into the caller's stream):
+//   symmetric  (ckks_sym.c:181-301):  [k_sample_cbd || k_sample_uniform(a -> c1)] -> k_encode_encrypt,
+//                                      or the per-prime software pipeline k_encode_rns / k_ntt_fuse
+//                                      beside the per-prime uniform sampler (encrypt_sym below)
 //   asymmetric (ckks_asym.c:173-286): k_sample_ternary(u, counter) -> k_sample_cbd(e0|e1 at
 //                                      counter base) -> k_encode_encrypt
 //   encode-only (BASELINE config 5):  k_encode_encrypt<EncodeOnly>
