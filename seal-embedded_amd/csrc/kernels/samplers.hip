@@ -138,6 +138,33 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
                 }
             }
         }
+        // ---- phase 0 (full batches, no helper waves): the first K0 redraw candidates up front ---
+        // The candidate counters are known before the bulk block is squeezed (it consumes exactly
+        // one), so every lane computes its first K0 candidates V[ctr .. ctr+K0) into LDS now, and the
+        // bulk phase patches a rejected word right after the 16-byte piece holding its marker was
+        // stored -- the line is still in L2, so the patch costs no HBM write of its own (patching
+        // after the whole polynomial has been written costs a 128-byte line per 4-byte patch: 1.64x
+        // write amplification).  K0 = mean - 1.5 sigma of the per-polynomial reject count (capped
+        // by LDS), so nearly every lane uses all of them; what is still rejected afterwards goes
+        // through the reject list and the balanced phase 2 as before.  The result does not depend
+        // on K0 (a candidate is only *consumed* when the lane needs one, in counter order).
+        uint32_t k0 = 0, cpos = 0;
+        uint32_t *lds_c0 = reinterpret_cast<uint32_t *>(pin_lds + 1024);  // [k0][blockDim.x]
+        if (!wg_pool && !(A.debug_flags & 2))
+        {
+            const float mean = (float)N * ((float)(0u - bound) * (1.0f / 4294967296.0f));
+            const float lo   = mean - 1.5f * sqrtf(mean);
+            k0               = lo > 0.0f ? (uint32_t)lo : 0u;
+            k0               = min(k0, min(64u, (uint32_t)((83u * 1024u) / (4u * blockDim.x))));
+            for (uint32_t c = 0; c < k0; c++)
+            {
+                KeccakState cs;
+                prng_absorb(cs, seed, ctr + c);
+                keccak_f1600_fresh(cs);  // only cs.lo[0] is consumed
+                lds_c0[c * blockDim.x + threadIdx.x] = cs.lo[0];
+            }
+        }
+
         if (active)
         {
             KeccakState st;
@@ -163,10 +190,28 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
                 {
                     if (mask != 0)
                     {
-                        const uint32_t p = (uint32_t)__clz((int)mask);
+                        const uint32_t p   = (uint32_t)__clz((int)mask);
+                        const uint32_t pos = first_pos + (p - (32u - count));
                         mask &= ~(0x80000000u >> p);
-                        if (nrej < A.rej_cap) mylist[nrej] = first_pos + (p - (32u - count));
-                        nrej++;
+                        // next accepted phase-0 candidate, if any is left: patch in place
+                        bool patched = false;
+                        while (cpos < k0)
+                        {
+                            const uint32_t x = lds_c0[cpos * blockDim.x + threadIdx.x];
+                            cpos++;
+                            ctr++;
+                            if (x < bound)
+                            {
+                                mypoly[pos] = barrett32(x, q, crh);
+                                patched     = true;
+                                break;
+                            }
+                        }
+                        if (!patched)
+                        {
+                            if (nrej < A.rej_cap) mylist[nrej] = pos;
+                            nrej++;
+                        }
                     }
                 }
             };
