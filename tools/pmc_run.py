@@ -16,6 +16,7 @@ src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 dst = torch.empty_like(src)
 dst.copy_(src); torch.cuda.synchronize()
 ctx = pkg.Context(n, npr); ctx.reserve(B); ctx.set_secret_key(V.secret_key(n))
+ctx.set_debug_flags(int(os.environ.get("SE_PMC_FLAGS", "0")))   # e.g. 2 = no redraw phase (traffic of the bulk alone)
 vals = torch.from_numpy(V.bench_values(B, n)).to(dev)
 ss_np, sd_np = V.bench_seeds(B)
 ss, sd = torch.from_numpy(ss_np).to(dev), torch.from_numpy(sd_np).to(dev)
