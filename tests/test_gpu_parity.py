@@ -681,7 +681,7 @@ def test_full_size_properties_config2(env):
     from oracle.pyoracle import Oracle
     torch = env["torch"]
     n, npr = 4096, 3
-    B = int(os.environ.get("SE_TEST_FULL_B", "16384"))
+    B = int(os.environ.get("SE_TEST_FULL_B", "65536"))   # BASELINE config 2 batch
     ctx = env["pkg"].Context(n, npr)
     sk = V.secret_key(n)
     ctx.set_secret_key(sk)
