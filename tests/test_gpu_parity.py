@@ -722,6 +722,75 @@ def test_full_size_properties_config2(env):
     assert bool((d0 == c0).all()) and bool((d1 == c1).all())
 
 
+def test_full_size_properties_config4(env):
+    """BASELINE config 4 shape at its per-GPU batch (n=16384, 6 primes, 32768 ciphertexts = 24 GiB
+    of output): the exact round-trip criterion through the on-GPU verifier for every ciphertext
+    (first and last prime), canonical ranges, oracle spot checks."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = 16384, 6
+    B = int(os.environ.get("SE_TEST_FULL_B4", "32768"))
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    base = V.bench_values(1024, n)
+    vals = np.tile(base, (B // 1024, 1))                 # seeds differ per ciphertext
+    ss, sd = V.bench_seeds(B)
+    dv, dss, dsd = dev_t(env, vals), dev_t(env, ss), dev_t(env, sd)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    ntt_pte = torch.zeros_like(c0)
+    status = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encrypt_sym(dv, dss, dsd, c0, c1, ntt_pte, None, status)
+    torch.cuda.synchronize()
+    assert bool(status.all())
+    dec = torch.zeros((B, n), dtype=torch.int32, device=env["dev"])
+    for j in (0, npr - 1):
+        q = o.q[j]
+        ctx.decrypt_decode(c0, c1, j, dec, None, None)
+        torch.cuda.synchronize()
+        assert bool((dec == ntt_pte[:, j, :]).all()), j
+        for t in (c0, c1):
+            assert int(t[:, j, :].max()) < q and int(t[:, j, :].min()) >= 0
+    for b in (0, 65, B - 1):
+        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b
+
+
+def test_full_size_properties_config3(env):
+    """BASELINE config 3 (public-key, n=4096, 3 primes) at batch 65536: canonical ranges,
+    determinism, oracle spot checks across the batch."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = 4096, 3
+    B = int(os.environ.get("SE_TEST_FULL_B", "65536"))
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    o = Oracle(n, npr)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    vals = V.bench_values(B, n)
+    _, sd = V.bench_seeds(B)
+    dv, dsd = dev_t(env, vals), dev_t(env, sd)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    status = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encrypt_asym(dv, dsd, c0, c1, status=status)
+    torch.cuda.synchronize()
+    assert bool(status.all())
+    for j in range(npr):
+        for t in (c0, c1):
+            assert int(t[:, j, :].max()) < o.q[j] and int(t[:, j, :].min()) >= 0
+    for b in (0, 1, 63, 64, 4097, B // 2 + 17, B - 1):
+        r = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b
+    d0, d1 = torch.zeros_like(c0), torch.zeros_like(c0)
+    ctx.encrypt_asym(dv, dsd, d0, d1)
+    torch.cuda.synchronize()
+    assert bool((d0 == c0).all()) and bool((d1 == c1).all())
+
+
 # --------------------------------------------------------------------------- reference API layer
 def test_reference_api_callback_stream(env, golden, tmp_path):
     """se_setup / se_encrypt_seeded through the drop-in symbols: 2*np callbacks of 4n bytes, c0
