@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     n, npr = rng.choice(SHAPES)
     big = n >= 8192
     B = rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 257, 300] if not big else [1, 2, 5, 33, 64, 65, 70])
-    mode = rng.choice(["sym", "sym", "asym", "host", "hostasym"])
+    mode = rng.choice(["sym", "sym", "asym", "host", "hostasym", "stage"])
     case_seed = rng.getrandbits(32)
     nr = np.random.default_rng(case_seed)
     key = (n, npr)
@@ -48,6 +48,48 @@ while time.time() - t0 < budget:
     ctx.set_pipeline(ov, sp)
     ctx.set_reject_list_capacity(rng.choice([0, 0, 0, 3, 40]) or max(256, n // 16))
     desc = f"seed={master} case={cases} n={n} np={npr} B={B} mode={mode} vals={kind} pipe=({ov},{sp}) case_seed={case_seed}"
+    if mode == "stage":
+        # stage-level operators: uniform sampler with random start counters, ternary -> CBD chain,
+        # NTT -> INTT round trip against the oracle's forward NTT, PRNG blocks of random lengths
+        import hashlib, struct
+        Bs = min(B, 70)
+        seeds = nr.integers(0, 256, (Bs, 64), dtype=np.uint8)
+        cin = nr.integers(0, 2 ** 40, Bs, dtype=np.int64)
+        out = torch.zeros((Bs, npr, n), dtype=torch.int32, device=dev)
+        cout = torch.zeros(Bs, dtype=torch.int64, device=dev)
+        ctx.sample_uniform(T(seeds), out, ctr_in=T(cin), ctr_out=cout)
+        codes = torch.zeros((Bs, n), dtype=torch.int8, device=dev); tctr = torch.zeros(Bs, dtype=torch.int64, device=dev)
+        ctx.sample_ternary(T(seeds), codes, tctr)
+        err = torch.zeros((Bs, 2 * n), dtype=torch.int8, device=dev)
+        ctx.sample_cbd(T(seeds), err, 2 * (n // 16), ctr_base=tctr)
+        j = rng.randrange(npr); q = int(o.q[j])
+        polys = nr.integers(0, q, (Bs, n), dtype=np.uint64).astype(np.uint32)
+        tp = T(polys.view(np.int32)).clone(); ctx.ntt(j, tp); fwd = tp.clone(); ctx.intt(j, tp)
+        outlen = rng.choice([1, 3, 8, 96, 135, 136, 137, 272, 1000])
+        pctr = nr.integers(0, 2 ** 62, Bs, dtype=np.int64)
+        pout = torch.zeros((Bs, outlen), dtype=torch.uint8, device=dev)
+        ctx.prng_blocks(T(seeds), T(pctr), pout, outlen)
+        torch.cuda.synchronize()
+        g, gc = out.cpu().numpy().view(np.uint32), cout.cpu().numpy()
+        gcodes, gt, ge = codes.cpu().numpy(), tctr.cpu().numpy(), err.cpu().numpy()
+        gf, gi, gp = fwd.cpu().numpy().view(np.uint32), tp.cpu().numpy().view(np.uint32), pout.cpu().numpy()
+        for b in sorted(set([0, Bs - 1, rng.randrange(Bs)])):
+            c = int(cin[b])
+            for jj in range(npr):
+                a, c = o.sample_uniform(jj, seeds[b].tobytes(), c)
+                if not (g[b, jj] == a).all(): print("MISMATCH uniform", desc, b, jj); sys.exit(1)
+            if int(gc[b]) != c: print("MISMATCH uniform ctr", desc, b); sys.exit(1)
+            u, c = o.sample_ternary_small(seeds[b].tobytes(), 0)
+            e0, c2 = o.cbd_int8(seeds[b].tobytes(), c); e1, _ = o.cbd_int8(seeds[b].tobytes(), c2)
+            if not ((ctx.pack_ternary(gcodes[b]) == u).all() and int(gt[b]) == c and (ge[b, :n] == e0).all() and (ge[b, n:] == e1).all()):
+                print("MISMATCH ternary/cbd", desc, b); sys.exit(1)
+            if not ((gf[b] == o.ntt(polys[b], j)).all() and (gi[b] == polys[b]).all()):
+                print("MISMATCH ntt/intt", desc, b); sys.exit(1)
+            if gp[b].tobytes() != hashlib.shake_256(seeds[b].tobytes() + struct.pack("<Q", int(pctr[b]))).digest(outlen):
+                print("MISMATCH prng", desc, b); sys.exit(1)
+            cts += 1
+        cases += 1
+        continue
     if mode in ("sym", "asym"):
         c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.zeros_like(c0)
         st = torch.zeros(B, dtype=torch.uint8, device=dev)
