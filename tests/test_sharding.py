@@ -73,3 +73,28 @@ def test_two_rank_gloo_gather_matches_single_process():
                                      V.secret_key(n), nthreads=1)
     assert got.shape == (total, 2, npr, n)
     assert (got[:, 0] == c0).all() and (got[:, 1] == c1).all()
+
+
+def test_bench_contract_constants():
+    """bench.py's workload table against SURVEY.md 8(d): algorithmic bytes per unit, batch sizes of
+    the BASELINE configs, and the JSON keys the driver parses (static checks: no GPU here)."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    tree = ast.parse(src)
+    wl = None
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "WORKLOADS":
+            wl = eval(compile(ast.Expression(node.value), "bench.py", "eval"))
+    assert wl is not None
+    assert wl["c2"] == (4096, 3, "sym", 65536, 106624)
+    assert wl["c3"] == (4096, 3, "asym", 65536, 106560)
+    assert wl["c4"] == (16384, 6, "sym", 32768, 819328)
+    assert wl["c5"] == (4096, 3, "encode", 262144, 57344)
+    assert wl["c1"] == (1024, 1, "sym", 1, 10368)
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"',
+                '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"',
+                '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"',
+                '"cores"', '"kind"', '"sample"'):
+        assert key in src, key
