@@ -12,6 +12,7 @@
 #include "se_context.h"
 #include "se_hostpipe.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -76,7 +77,15 @@ int Context::init(size_t n, size_t nprimes, int dev)
     dp = to_dev_params(hp);
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
     // rej_cap >= 3x the expected rejections per polynomial; spec_cap ~ mean + >5 sigma of the draws
-    spec_cap = (uint32_t)(n <= 2048 ? 32 : n / 32);
+    // speculation capacity: the helper waves compute this many candidates per polynomial WHILE the
+    // chains squeeze n*4/136 blocks, and the chains wait for them -- more than the chains need is
+    // pure critical path.  mean + 4 sigma of the draws per polynomial (30-bit primes: reject
+    // probability 0.0186; draws beyond the capacity go through the pooled loop), multiple of 16.
+    {
+        const double mean = (double)n * 0.0186 * 1.02;
+        uint32_t cap      = (uint32_t)(mean + 4.0 * sqrt((double)n * 0.0186) + 15.0) & ~15u;
+        spec_cap          = n <= 2048 ? 32u : cap;
+    }
 
     std::vector<uint16_t> inv;
     host_index_map(hp, index_map, inv);
