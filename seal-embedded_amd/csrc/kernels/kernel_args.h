@@ -71,6 +71,23 @@ hipError_t launch_ntt_polys(const DevParams &, const DevTables &, int j, uint32_
 hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, size_t count,
                              hipStream_t);
 hipError_t launch_sample_uniform(const DevParams &, const UniformArgs &, hipStream_t);
+// Small-batch prime speculation (se_context.cpp, encrypt_sym_small): the uniform sampler of prime
+// j >= 1 is run for every plausible start counter of a window at once ("virtual ciphertexts"), so
+// the primes of one ciphertext no longer wait for each other.
+struct SpecPlan
+{
+    uint32_t nprimes;              // primes of the chain (speculated: 1 .. nprimes-1)
+    uint32_t B;                    // real ciphertexts
+    uint64_t base[kMaxPrimes];     // first guessed start counter of prime j
+    uint32_t count[kMaxPrimes];    // guesses per ciphertext for prime j (0 for j = 0)
+    uint32_t offset[kMaxPrimes];   // first virtual ciphertext of prime j
+    uint32_t total;                // virtual ciphertexts in all
+};
+hipError_t launch_spec_setup(const SpecPlan &, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v,
+                             hipStream_t);
+hipError_t launch_spec_select(const SpecPlan &, uint32_t n, const uint64_t *ctr0, const uint64_t *ctrout_v,
+                              const uint32_t *rows, uint32_t *c1, uint32_t *fail, hipStream_t);
+
 hipError_t launch_sample_cbd(const CbdArgs &, hipStream_t);
 hipError_t launch_sample_ternary(const TernaryArgs &, hipStream_t);
 hipError_t launch_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs, uint8_t *out,

@@ -664,6 +664,74 @@ hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Small-batch prime speculation.  Prime j+1 of a ciphertext starts at the PRNG counter where prime
+// j's redraws stopped, which makes the primes of ONE ciphertext a sequential chain of np long
+// squeezes -- all there is to do when the batch is a single ciphertext.  The stop counter is
+// 1 + (draws consumed) with draws ~ Binomial(n, p) plus a few rejected candidates: a narrow window.
+// So the sampler of prime j is run for EVERY start counter of that window as independent "virtual
+// ciphertexts" (same seed, guessed counter, own output row), all primes at once, and afterwards
+// the true chain is followed through the results: c_1 = end of prime 0, pick guess c_1 - base_1,
+// take its end counter as c_2, ...  A counter outside a window sets fail[b]; the caller then redoes
+// that batch sequentially.  Idle lanes are free in a one-ciphertext call; the latency drops from np
+// squeezes to one.
+// ------------------------------------------------------------------------------------------
+__global__ void k_spec_setup(SpecPlan S, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.total) return;
+    uint32_t j = 1;
+    while (j + 1 < S.nprimes && v >= S.offset[j + 1]) j++;
+    const uint32_t r = v - S.offset[j];
+    const uint32_t b = r / S.count[j], g = r - b * S.count[j];
+    const uint4 *src = reinterpret_cast<const uint4 *>(seeds + (size_t)b * kSeedBytes);
+    uint4 *dst       = reinterpret_cast<uint4 *>(seeds_v + (size_t)v * kSeedBytes);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dst[i] = src[i];
+    ctr_v[v] = S.base[j] + g;
+}
+
+// one workgroup per real ciphertext: follow the counter chain through the guesses and copy the
+// selected rows into c1[b][j][:]
+__global__ __launch_bounds__(256) void k_spec_select(SpecPlan S, uint32_t n, const uint64_t *ctr0,
+                                                     const uint64_t *ctrout_v, const uint32_t *rows,
+                                                     uint32_t *c1, uint32_t *fail)
+{
+    const uint32_t b = blockIdx.x;
+    uint64_t ctr     = ctr0[b];
+    for (uint32_t j = 1; j < S.nprimes; j++)
+    {
+        const uint64_t g = ctr - S.base[j];   // wraps to a huge value when ctr < base
+        if (g >= S.count[j])
+        {
+            if (threadIdx.x == 0) fail[b] = j;
+            return;
+        }
+        const size_t v      = (size_t)S.offset[j] + (size_t)b * S.count[j] + (size_t)g;
+        const uint4 *src    = reinterpret_cast<const uint4 *>(rows + v * n);
+        uint4 *dst          = reinterpret_cast<uint4 *>(c1 + ((size_t)b * S.nprimes + j) * n);
+        for (uint32_t i = threadIdx.x; i < n / 4; i += blockDim.x) dst[i] = src[i];
+        ctr = ctrout_v[v];
+    }
+    if (threadIdx.x == 0) fail[b] = 0;
+}
+
+hipError_t launch_spec_setup(const SpecPlan &S, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v,
+                             hipStream_t st)
+{
+    if (S.total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spec_setup, dim3((S.total + 255) / 256), dim3(256), 0, st, S, seeds, seeds_v, ctr_v);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_select(const SpecPlan &S, uint32_t n, const uint64_t *ctr0, const uint64_t *ctrout_v,
+                              const uint32_t *rows, uint32_t *c1, uint32_t *fail, hipStream_t st)
+{
+    if (S.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spec_select, dim3(S.B), dim3(256), 0, st, S, n, ctr0, ctrout_v, rows, c1, fail);
+    return hipGetLastError();
+}
+
 hipError_t launch_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs, uint8_t *out,
                               uint32_t outlen, uint32_t count, hipStream_t st)
 {

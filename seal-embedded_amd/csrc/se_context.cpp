@@ -47,8 +47,11 @@ Context::~Context()
     if (ev_enc) (void)hipEventDestroy(ev_enc);
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
+    for (auto &sp : sp_streams)
+        if (sp) (void)hipStreamDestroy(sp);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
-                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec};
+                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec,
+                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -404,6 +407,135 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     stage_begin(5, st);
     SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)np - 1, B, st));
     stage_end(st);
+    return 0;
+}
+
+// ---- small-batch prime speculation -----------------------------------------------------------
+bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
+{
+    const uint32_t np = (uint32_t)hp.nprimes;
+    if (!overlap || !have_sk || np < 2 || B == 0 || B > 64) return false;
+    plan         = SpecPlan{};
+    plan.nprimes = np;
+    plan.B       = (uint32_t)B;
+    const double n     = (double)hp.n;
+    const double width = (debug_flags & 256) ? 0.0 : 5.5;  // 256: windows of one guess (forces the fallback)
+    double mu = 0.0, var = 0.0;
+    uint64_t off = 0;
+    for (uint32_t j = 1; j < np; j++)
+    {
+        // prime j-1 consumed 1 block + (draws) counters; draws ~ Binomial(n, p)/(1 - p)
+        const double p = (double)(0u - dp.bound[j - 1]) / 4294967296.0;
+        mu += 1.0 + n * p / (1.0 - p);
+        var += n * p * 1.06;
+        const uint64_t h = (debug_flags & 256) ? 0 : (uint64_t)(width * sqrt(var)) + 2;
+        const uint64_t c = (uint64_t)(mu + 0.5);
+        plan.base[j]     = c > h ? c - h : 0;
+        plan.count[j]    = (uint32_t)(2 * h + 1);
+        plan.offset[j]   = (uint32_t)off;
+        off += (uint64_t)B * plan.count[j];
+        if (off > 4096) return false;  // more virtual ciphertexts than it is worth
+    }
+    plan.total = (uint32_t)off;
+    return true;
+}
+
+int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, const uint8_t *d_share_seeds,
+                               const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
+                               uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, hipStream_t st)
+{
+    if (!d_values || !d_share_seeds || !d_seeds || !d_c0 || !d_c1) return kErrInvalid;
+    SEAMD_HIP(hipSetDevice(device));
+    const size_t B     = plan.B;
+    const uint32_t n   = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
+    const size_t total = plan.total;
+    int rc             = ensure_scratch(B + total);  // reject lists / candidates of the virtual ciphertexts too
+    if (rc) return rc;
+    if (total > sp_cap)
+    {
+        SEAMD_HIP(hipDeviceSynchronize());
+        void *old[] = {d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows};
+        for (void *p : old)
+            if (p) (void)hipFree(p);
+        d_sp_seeds = nullptr, d_sp_ctr = nullptr, d_sp_ctrout = nullptr, d_sp_rows = nullptr;
+        sp_cap = 0;
+        SEAMD_HIP(hipMalloc((void **)&d_sp_seeds, total * 64));
+        SEAMD_HIP(hipMalloc((void **)&d_sp_ctr, total * sizeof(uint64_t)));
+        SEAMD_HIP(hipMalloc((void **)&d_sp_ctrout, total * sizeof(uint64_t)));
+        SEAMD_HIP(hipMalloc((void **)&d_sp_rows, total * (size_t)n * sizeof(uint32_t)));
+        sp_cap = total;
+    }
+    if (B > sp_fail_cap)
+    {
+        SEAMD_HIP(hipDeviceSynchronize());
+        if (d_sp_fail) (void)hipFree(d_sp_fail);
+        d_sp_fail = nullptr, sp_fail_cap = 0;
+        SEAMD_HIP(hipMalloc((void **)&d_sp_fail, 64 * sizeof(uint32_t)));
+        sp_fail_cap = 64;
+    }
+    for (uint32_t j = 1; j < np; j++)
+        if (!sp_streams[j]) SEAMD_HIP(hipStreamCreateWithFlags(&sp_streams[j], hipStreamNonBlocking));
+
+    CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
+    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
+
+    //   S   : U_0 (real ciphertexts) ───────────────┐ (wait all) select ► (wait A) N_0 .. N_{np-1}
+    //   A   : cbd ► k_encode_rns ───────────────────┤
+    //   P_1 : setup ► U_1 (guesses) ────────────────┤
+    //   P_j :        (wait setup) U_j (guesses) ────┘
+    SEAMD_HIP(hipEventRecord(ev_fork, st));
+    SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+    for (uint32_t j = 1; j < np; j++) SEAMD_HIP(hipStreamWaitEvent(sp_streams[j], ev_fork, 0));
+
+    stage_begin(0, aux_stream);
+    SEAMD_HIP(launch_sample_cbd(ca, aux_stream));
+    stage_end(aux_stream);
+    stage_begin(4, aux_stream);
+    SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, aux_stream));
+    stage_end(aux_stream);
+    SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
+
+    SEAMD_HIP(launch_spec_setup(plan, d_share_seeds, d_sp_seeds, d_sp_ctr, sp_streams[1]));
+    SEAMD_HIP(hipEventRecord(ev_enc, sp_streams[1]));
+
+    UniformArgs u0{d_share_seeds, nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, 1, np,
+                   d_spec,        spec_cap, 0,     debug_flags};
+    stage_begin(1, st);
+    SEAMD_HIP(launch_sample_uniform(dp, u0, st));
+    stage_end(st);
+
+    for (uint32_t j = 1; j < np; j++)
+    {
+        hipStream_t sj = sp_streams[j];
+        if (j > 1) SEAMD_HIP(hipStreamWaitEvent(sj, ev_enc, 0));
+        const size_t off = plan.offset[j], cnt = B * plan.count[j];
+        // the kernel addresses row (b * out_primes + prime) * n: out_primes = 1, so shift by j rows
+        UniformArgs uj{d_sp_seeds + off * 64,
+                       d_sp_ctr + off,
+                       d_sp_ctrout + off,
+                       d_sp_rows + off * n - (size_t)j * n,
+                       d_rej + (B + off) * rej_cap,
+                       rej_cap,
+                       (uint32_t)cnt,
+                       j,
+                       j + 1,
+                       1,
+                       d_spec + (B + off) * spec_cap,
+                       spec_cap,
+                       0,
+                       debug_flags};
+        SEAMD_HIP(launch_sample_uniform(dp, uj, sj));
+        SEAMD_HIP(hipEventRecord(ev_prime[j], sj));
+        SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[j], 0));
+    }
+    SEAMD_HIP(launch_spec_select(plan, n, d_ctr, d_sp_ctrout, d_sp_rows, d_c1, d_sp_fail, st));
+    SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    for (uint32_t j = 0; j < np; j++)
+    {
+        stage_begin(5, st);
+        SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)j, B, st));
+        stage_end(st);
+    }
     return 0;
 }
 

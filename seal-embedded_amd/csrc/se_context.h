@@ -55,6 +55,14 @@ struct Context
     uint32_t spec_cap  = 128;
     uint32_t *d_a      = nullptr;  // [a_cap][np][n]: `a` when the caller does not want c1 back
     size_t a_cap       = 0;
+    // small-batch prime speculation (encrypt_sym_small): virtual-ciphertext scratch and streams
+    uint8_t *d_sp_seeds   = nullptr;  // [sp_cap][64]
+    uint64_t *d_sp_ctr    = nullptr;  // [sp_cap] guessed start counters
+    uint64_t *d_sp_ctrout = nullptr;  // [sp_cap] end counters under each guess
+    uint32_t *d_sp_rows   = nullptr;  // [sp_cap][n] a_j under each guess
+    uint32_t *d_sp_fail   = nullptr;  // [sp_fail_cap] 0 = chain resolved, j = window of prime j missed
+    size_t sp_cap = 0, sp_fail_cap = 0;
+    hipStream_t sp_streams[kMaxPrimes] = {};
     size_t scratch_cap = 0;
     uint32_t rej_cap   = 256;
     uint32_t debug_flags = 0;  // timing ablations of the uniform sampler (tests/tools only)
@@ -96,6 +104,14 @@ struct Context
                      hipStream_t st);
     int encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_t *d_pte,
                    uint8_t *d_status, hipStream_t st);
+    // Small batches (a handful of ciphertexts): all primes' uniform samplers at once under guessed
+    // start counters (kernels/samplers.hip, k_spec_*).  small_batch_plan says whether a batch
+    // qualifies; after encrypt_sym_small the caller must read d_sp_fail[0..B) and redo the batch
+    // with encrypt_sym if any entry is non-zero (a counter fell outside its window: ~1e-7).
+    bool small_batch_plan(size_t B, SpecPlan &plan) const;
+    int encrypt_sym_small(const SpecPlan &plan, const float *d_values, const uint8_t *d_share_seeds,
+                          const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,
+                          int64_t *d_pte, uint8_t *d_status, hipStream_t st);
 
     void stage_begin(int stage, hipStream_t st);
     void stage_end(hipStream_t st);

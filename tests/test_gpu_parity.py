@@ -630,6 +630,31 @@ def test_magnitude_classes_through_every_path(env, n, npr):
                 assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all(), (split, b)
 
 
+@pytest.mark.parametrize("n,npr,B", [(4096, 3, 1), (4096, 3, 5), (4096, 2, 16), (8192, 6, 2), (16384, 6, 1),
+                                       (16384, 3, 2)])
+def test_small_batch_prime_speculation(env, n, npr, B):
+    """Host-pointer calls with a handful of ciphertexts run every prime's uniform sampler at once
+    under guessed start counters (k_spec_*, Context::encrypt_sym_small) and then follow the true
+    counter chain through the guesses.  Results must equal the oracle's; with debug flag 256 every
+    window has a single guess, so the chain misses and the call is redone sequentially."""
+    from oracle.pyoracle import Oracle
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=3)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n, first=31)
+    ss, sd = V.bench_seeds(B, first=900)
+    exp = [o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk) for b in range(B)]
+    for flags in (0, 256):
+        ctx.set_debug_flags(flags)
+        for rep in range(2):                       # second call reuses streams and scratch
+            r = ctx.encrypt_sym_host(vals, ss, sd, want_extra=True)
+            assert r["failed"] == 0
+            for b in range(B):
+                assert (r["c0"][b] == exp[b]["c0"]).all() and (r["c1"][b] == exp[b]["c1"]).all(), (flags, b)
+                assert (r["ntt_pte"][b] == exp[b]["ntt_pte"]).all() and (r["pte"][b] == exp[b]["pte"]).all()
+
+
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 129])
 def test_ragged_batch_sizes(env, B):
     from oracle.pyoracle import Oracle
