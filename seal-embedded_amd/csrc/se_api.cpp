@@ -44,8 +44,8 @@ int se_amd_create(se_amd_ctx **out, size_t degree, size_t nprimes, int device)
     if (!out) return SE_ERR_INVALD_ARGUMENT;
     *out          = nullptr;
     // The small-batch path runs one sampler launch per prime on streams of their own; with the ROCm
-    // default of 4 hardware queues per process some of them share a queue and serialise (n = 4096:
-    // 3.3 ms per call instead of 1.8 ms).  Ask for more queues unless the caller decided otherwise;
+    // default of 4 hardware queues per process some of them share a queue and serialise (n = 16384 /
+    // 6 primes: 12.9 ms per call instead of 7.0 ms; 3-prime chains fit 4 queues).  Ask for more queues unless the caller decided otherwise;
     // only effective when this is the first HIP use of the process (the C-API case).
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     se_amd_ctx *h = new (std::nothrow) se_amd_ctx();

@@ -48,7 +48,7 @@ Context::~Context()
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
     for (auto &sp : sp_streams)
-        if (sp) (void)hipStreamDestroy(sp);
+        if (sp && sp != aux_stream) (void)hipStreamDestroy(sp);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
                     d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec,
                     d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail};
@@ -473,7 +473,10 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
         SEAMD_HIP(hipMalloc((void **)&d_sp_fail, 64 * sizeof(uint32_t)));
         sp_fail_cap = 64;
     }
-    for (uint32_t j = 1; j < np; j++)
+    // prime 1 rides on the auxiliary stream behind the (tiny) cbd / encode kernels: with the runtime's
+    // default of 4 hardware queues a 3-prime call then has a queue per concurrent launch
+    sp_streams[1] = aux_stream;
+    for (uint32_t j = 2; j < np; j++)
         if (!sp_streams[j]) SEAMD_HIP(hipStreamCreateWithFlags(&sp_streams[j], hipStreamNonBlocking));
 
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
@@ -481,11 +484,11 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
 
     //   S   : U_0 (real ciphertexts) ───────────────┐ (wait all) select ► (wait A) N_0 .. N_{np-1}
     //   A   : cbd ► k_encode_rns ───────────────────┤
-    //   P_1 : setup ► U_1 (guesses) ────────────────┤
-    //   P_j :        (wait setup) U_j (guesses) ────┘
+    //         └► setup ► U_1 (guesses) ─────────────┤
+    //   P_j :        (wait setup) U_j (guesses) ────┘   (j >= 2)
     SEAMD_HIP(hipEventRecord(ev_fork, st));
     SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
-    for (uint32_t j = 1; j < np; j++) SEAMD_HIP(hipStreamWaitEvent(sp_streams[j], ev_fork, 0));
+    for (uint32_t j = 2; j < np; j++) SEAMD_HIP(hipStreamWaitEvent(sp_streams[j], ev_fork, 0));
 
     stage_begin(0, aux_stream);
     SEAMD_HIP(launch_sample_cbd(ca, aux_stream));
