@@ -414,7 +414,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
 bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
 {
     const uint32_t np = (uint32_t)hp.nprimes;
-    if (!overlap || !have_sk || np < 2 || B == 0 || B > 64) return false;
+    if (!overlap || !have_sk || np < 2 || B == 0 || B > 1024) return false;
     plan         = SpecPlan{};
     plan.nprimes = np;
     plan.B       = (uint32_t)B;
@@ -434,7 +434,7 @@ bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
         plan.count[j]    = (uint32_t)(2 * h + 1);
         plan.offset[j]   = (uint32_t)off;
         off += (uint64_t)B * plan.count[j];
-        if (off > 4096) return false;  // more virtual ciphertexts than it is worth
+        if (off > (uint64_t)small_limit) return false;  // beyond this it stops paying
     }
     plan.total = (uint32_t)off;
     return true;
@@ -470,8 +470,8 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
         SEAMD_HIP(hipDeviceSynchronize());
         if (d_sp_fail) (void)hipFree(d_sp_fail);
         d_sp_fail = nullptr, sp_fail_cap = 0;
-        SEAMD_HIP(hipMalloc((void **)&d_sp_fail, 64 * sizeof(uint32_t)));
-        sp_fail_cap = 64;
+        SEAMD_HIP(hipMalloc((void **)&d_sp_fail, 1024 * sizeof(uint32_t)));
+        sp_fail_cap = 1024;
     }
     // prime 1 rides on the auxiliary stream behind the (tiny) cbd / encode kernels: with the runtime's
     // default of 4 hardware queues a 3-prime call then has a queue per concurrent launch

@@ -1,6 +1,7 @@
 // se_context.h -- internal: the per-parameter-set GPU context behind the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -62,6 +63,7 @@ struct Context
     uint32_t *d_sp_rows   = nullptr;  // [sp_cap][n] a_j under each guess
     uint32_t *d_sp_fail   = nullptr;  // [sp_fail_cap] 0 = chain resolved, j = window of prime j missed
     size_t sp_cap = 0, sp_fail_cap = 0;
+    uint32_t small_limit = getenv("SE_AMD_SMALL_LIMIT") ? (uint32_t)atoi(getenv("SE_AMD_SMALL_LIMIT")) : 65536;  // virtual ciphertexts a small call may fan out to
     hipStream_t sp_streams[kMaxPrimes] = {};
     size_t scratch_cap = 0;
     uint32_t rej_cap   = 256;

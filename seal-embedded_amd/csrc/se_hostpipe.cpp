@@ -367,8 +367,8 @@ int HostPipe::run(Context &c, bool asym, const float *values, size_t B, const ui
     if (small)
     {
         // did every counter chain stay inside its guess windows?  (misses: ~1e-7 per prime)
-        uint32_t fail[64];
-        SEAMD_HIP(hipMemcpy(fail, c.d_sp_fail, B * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> fail(B);
+        SEAMD_HIP(hipMemcpy(fail.data(), c.d_sp_fail, B * sizeof(uint32_t), hipMemcpyDeviceToHost));
         bool any = false;
         for (size_t i = 0; i < B; i++) any = any || fail[i] != 0;
         if (any)
