@@ -35,6 +35,8 @@ struct UniformArgs
     uint32_t master_waves; // waves of a workgroup that own ciphertexts (the rest are redraw helpers)
     uint32_t debug_flags;  // ablation (timing experiments only): 2 = no phase 2 (wrong results);
                            // 8 = no helper waves, 16 = helpers without speculation (results stay correct)
+    uint32_t out_prime_base;  // output row of prime j is (b * out_primes + j - out_prime_base): lets a
+                              // single-prime launch (prime_lo = j) write one row per ciphertext
     uint32_t helper_fill;  // waves per workgroup that small batches are filled up to with helpers
                            // (0 = default 8 = two per SIMD; 4 leaves room for a co-resident
                            // 1024-thread transform workgroup at n = 16384)

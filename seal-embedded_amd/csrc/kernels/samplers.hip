@@ -103,7 +103,7 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
     for (uint32_t j = A.prime_lo; j < A.prime_hi; j++)
     {
         const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
-        uint32_t *mypoly = A.out + (b * A.out_primes + j) * (size_t)N;
+        uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
 
         uint32_t nrej = 0;
         const uint64_t bulk_ctr = ctr;   // the 4n-byte block; redraw candidates follow at ctr + 1 ..

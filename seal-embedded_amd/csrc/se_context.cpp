@@ -376,7 +376,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
                        j,             j + 1,               np,    d_spec,      spec_cap,
-                       0,             debug_flags,         fill};
+                       0,             debug_flags,         0,     fill};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
         stage_end(st);
@@ -512,11 +512,11 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
         hipStream_t sj = sp_streams[j];
         if (j > 1) SEAMD_HIP(hipStreamWaitEvent(sj, ev_enc, 0));
         const size_t off = plan.offset[j], cnt = B * plan.count[j];
-        // the kernel addresses row (b * out_primes + prime) * n: out_primes = 1, so shift by j rows
+        // one output row per virtual ciphertext: out_primes = 1, rows counted from prime j
         UniformArgs uj{d_sp_seeds + off * 64,
                        d_sp_ctr + off,
                        d_sp_ctrout + off,
-                       d_sp_rows + off * n - (size_t)j * n,
+                       d_sp_rows + off * n,
                        d_rej + (B + off) * rej_cap,
                        rej_cap,
                        (uint32_t)cnt,
@@ -526,7 +526,8 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
                        d_spec + (B + off) * spec_cap,
                        spec_cap,
                        0,
-                       debug_flags};
+                       debug_flags,
+                       j};
         SEAMD_HIP(launch_sample_uniform(dp, uj, sj));
         SEAMD_HIP(hipEventRecord(ev_prime[j], sj));
         SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[j], 0));
