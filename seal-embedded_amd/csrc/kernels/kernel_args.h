@@ -35,6 +35,8 @@ struct UniformArgs
     uint32_t master_waves; // waves of a workgroup that own ciphertexts (the rest are redraw helpers)
     uint32_t debug_flags;  // ablation (timing experiments only): 2 = no phase 2 (wrong results);
                            // 8 = no helper waves, 16 = helpers without speculation (results stay correct)
+    const uint32_t *only_from;  // optional [B]: ciphertext b takes part only if only_from[b] != 0 and
+                                // prime_lo >= only_from[b] (redo of speculation misses)
     uint32_t out_prime_base;  // output row of prime j is (b * out_primes + j - out_prime_base): lets a
                               // single-prime launch (prime_lo = j) write one row per ciphertext
     uint32_t helper_fill;  // waves per workgroup that small batches are filled up to with helpers
@@ -87,7 +89,7 @@ struct SpecPlan
 };
 hipError_t launch_spec_setup(const SpecPlan &, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v,
                              hipStream_t);
-hipError_t launch_spec_select(const SpecPlan &, uint32_t n, const uint64_t *ctr0, const uint64_t *ctrout_v,
+hipError_t launch_spec_select(const SpecPlan &, uint32_t n, uint64_t *ctr0, const uint64_t *ctrout_v,
                               const uint32_t *rows, uint32_t *c1, uint32_t *fail, hipStream_t);
 
 hipError_t launch_sample_cbd(const CbdArgs &, hipStream_t);

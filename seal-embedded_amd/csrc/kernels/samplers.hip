@@ -79,7 +79,10 @@ __global__ __launch_bounds__(1024) void k_sample_uniform(DevParams P, UniformArg
     const uint32_t mthreads = A.master_waves * 64;
     const bool master = threadIdx.x < mthreads;
     const size_t bq   = (size_t)blockIdx.x * mthreads + threadIdx.x;
-    const bool active = master && bq < A.B;   // lanes past the batch stay alive as redraw helpers
+    // lanes past the batch (or masked out of a redo launch) stay alive as redraw helpers
+    const bool active = master && bq < A.B &&
+                        (!A.only_from || (A.only_from[bq] != 0 && A.prime_lo >= A.only_from[bq]));
+    if (A.only_from && !__syncthreads_or(active)) return;  // redo launch with nothing to redo here
     const size_t b    = active ? bq : (size_t)A.B - 1;
     const bool wg_pool = blockDim.x > mthreads;   // helper waves present: pool the whole workgroup
 
@@ -672,8 +675,9 @@ hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
 // So the sampler of prime j is run for EVERY start counter of that window as independent "virtual
 // ciphertexts" (same seed, guessed counter, own output row), all primes at once, and afterwards
 // the true chain is followed through the results: c_1 = end of prime 0, pick guess c_1 - base_1,
-// take its end counter as c_2, ...  A counter outside a window sets fail[b]; the caller then redoes
-// that batch sequentially.  Idle lanes are free in a one-ciphertext call; the latency drops from np
+// take its end counter as c_2, ...  A counter outside a window sets fail[b] = j and leaves the true
+// counter in ctr0[b]; the caller then launches the ordinary per-prime chain masked to those
+// ciphertexts (UniformArgs::only_from), which normally finds nothing to do.  Idle lanes are free in a one-ciphertext call; the latency drops from np
 // squeezes to one.
 // ------------------------------------------------------------------------------------------
 __global__ void k_spec_setup(SpecPlan S, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v)
@@ -693,7 +697,7 @@ __global__ void k_spec_setup(SpecPlan S, const uint8_t *seeds, uint8_t *seeds_v,
 
 // one workgroup per real ciphertext: follow the counter chain through the guesses and copy the
 // selected rows into c1[b][j][:]
-__global__ __launch_bounds__(256) void k_spec_select(SpecPlan S, uint32_t n, const uint64_t *ctr0,
+__global__ __launch_bounds__(256) void k_spec_select(SpecPlan S, uint32_t n, uint64_t *ctr0,
                                                      const uint64_t *ctrout_v, const uint32_t *rows,
                                                      uint32_t *c1, uint32_t *fail)
 {
@@ -704,7 +708,12 @@ __global__ __launch_bounds__(256) void k_spec_select(SpecPlan S, uint32_t n, con
         const uint64_t g = ctr - S.base[j];   // wraps to a huge value when ctr < base
         if (g >= S.count[j])
         {
-            if (threadIdx.x == 0) fail[b] = j;
+            // miss: prime j .. np-1 of this ciphertext are redone sequentially from this counter
+            if (threadIdx.x == 0)
+            {
+                fail[b] = j;
+                ctr0[b] = ctr;
+            }
             return;
         }
         const size_t v      = (size_t)S.offset[j] + (size_t)b * S.count[j] + (size_t)g;
@@ -724,7 +733,7 @@ hipError_t launch_spec_setup(const SpecPlan &S, const uint8_t *seeds, uint8_t *s
     return hipGetLastError();
 }
 
-hipError_t launch_spec_select(const SpecPlan &S, uint32_t n, const uint64_t *ctr0, const uint64_t *ctrout_v,
+hipError_t launch_spec_select(const SpecPlan &S, uint32_t n, uint64_t *ctr0, const uint64_t *ctrout_v,
                               const uint32_t *rows, uint32_t *c1, uint32_t *fail, hipStream_t st)
 {
     if (S.B == 0) return hipSuccess;

@@ -305,6 +305,13 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     if (B == 0) return 0;
     if (!d_values || !d_share_seeds || !d_seeds || !d_c0 || !d_c1) return kErrInvalid;
     SEAMD_HIP(hipSetDevice(device));
+    {
+        // a handful of ciphertexts: latency path (all primes' samplers at once, prime speculation)
+        SpecPlan plan;
+        if (split_mode == 2 && small_batch_plan(B, plan))
+            return encrypt_sym_small(plan, d_values, d_share_seeds, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte,
+                                     d_status, st);
+    }
     int rc = ensure_scratch(B);
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
@@ -376,7 +383,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
                        j,             j + 1,               np,    d_spec,      spec_cap,
-                       0,             debug_flags,         0,     fill};
+                       0,             debug_flags,         nullptr, 0, fill};
         stage_begin(1, st);
         SEAMD_HIP(launch_sample_uniform(dp, ua, st));
         stage_end(st);
@@ -527,12 +534,21 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
                        spec_cap,
                        0,
                        debug_flags,
+                       nullptr,
                        j};
         SEAMD_HIP(launch_sample_uniform(dp, uj, sj));
         SEAMD_HIP(hipEventRecord(ev_prime[j], sj));
         SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[j], 0));
     }
     SEAMD_HIP(launch_spec_select(plan, n, d_ctr, d_sp_ctrout, d_sp_rows, d_c1, d_sp_fail, st));
+    // misses (~1e-7 per prime): the ordinary per-prime chain, masked to the ciphertexts that missed;
+    // without a miss every workgroup of these launches returns at once
+    for (uint32_t j = 1; j < np; j++)
+    {
+        UniformArgs ur{d_share_seeds, d_ctr,    d_ctr, d_c1,        d_rej,     rej_cap, (uint32_t)B, j, j + 1, np,
+                       d_spec,        spec_cap, 0,     debug_flags, d_sp_fail, 0,       0};
+        SEAMD_HIP(launch_sample_uniform(dp, ur, st));
+    }
     SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
     for (uint32_t j = 0; j < np; j++)
     {

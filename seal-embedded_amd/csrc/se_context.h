@@ -108,8 +108,8 @@ struct Context
                    uint8_t *d_status, hipStream_t st);
     // Small batches (a handful of ciphertexts): all primes' uniform samplers at once under guessed
     // start counters (kernels/samplers.hip, k_spec_*).  small_batch_plan says whether a batch
-    // qualifies; after encrypt_sym_small the caller must read d_sp_fail[0..B) and redo the batch
-    // with encrypt_sym if any entry is non-zero (a counter fell outside its window: ~1e-7).
+    // qualifies (encrypt_sym dispatches on it).  A counter outside its window (~1e-7 per prime) is
+    // redone on the device by the masked per-prime chain that follows the selection.
     bool small_batch_plan(size_t B, SpecPlan &plan) const;
     int encrypt_sym_small(const SpecPlan &plan, const float *d_values, const uint8_t *d_share_seeds,
                           const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,

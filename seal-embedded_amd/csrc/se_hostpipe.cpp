@@ -249,10 +249,6 @@ int HostPipe::run(Context &c, bool asym, const float *values, size_t B, const ui
 
     auto chunk_count = [&](size_t k) { return std::min(chunk, B - k * chunk); };
 
-    // single small symmetric batch: latency path with prime speculation (se_context.cpp)
-    SpecPlan plan;
-    const bool small = !asym && c1 && nch == 1 && !no_small && c.small_batch_plan(B, plan);
-
     auto launch_chunk = [&](size_t k) -> int {
         Slot &s          = slot[k % kSlots];
         const size_t lo  = k * chunk, cnt = chunk_count(k);
@@ -274,12 +270,6 @@ int HostPipe::run(Context &c, bool asym, const float *values, size_t B, const ui
             r = c.encrypt_asym((const float *)s.values, cnt, (const uint8_t *)s.seeds,
                                (uint32_t *)s.c0, (uint32_t *)s.c1, ntt_pte ? (uint32_t *)s.ntt_pte : nullptr,
                                pte ? (int64_t *)s.pte : nullptr, st, compute);
-        else if (small)
-            // a handful of ciphertexts: all primes' samplers at once under guessed counters
-            r = c.encrypt_sym_small(plan, (const float *)s.values, (const uint8_t *)s.share_seeds,
-                                    (const uint8_t *)s.seeds, (uint32_t *)s.c0, (uint32_t *)s.c1,
-                                    ntt_pte ? (uint32_t *)s.ntt_pte : nullptr,
-                                    pte ? (int64_t *)s.pte : nullptr, st, compute);
         else
             r = c.encrypt_sym((const float *)s.values, cnt, (const uint8_t *)s.share_seeds,
                               (const uint8_t *)s.seeds, (uint32_t *)s.c0, (uint32_t *)s.c1,
@@ -364,21 +354,6 @@ int HostPipe::run(Context &c, bool asym, const float *values, size_t B, const ui
     if (e1 != hipSuccess) return hip_fail(e1, "hipStreamSynchronize(copy)");
     if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize(compute)");
 
-    if (small)
-    {
-        // did every counter chain stay inside its guess windows?  (misses: ~1e-7 per prime)
-        std::vector<uint32_t> fail(B);
-        SEAMD_HIP(hipMemcpy(fail.data(), c.d_sp_fail, B * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        bool any = false;
-        for (size_t i = 0; i < B; i++) any = any || fail[i] != 0;
-        if (any)
-        {
-            no_small = true;  // redo this call on the sequential path
-            int r    = run(c, asym, values, B, share_seeds, seeds, c0, c1, ntt_pte, pte, status);
-            no_small = false;
-            return r;
-        }
-    }
     std::vector<uint8_t> st(B);
     SEAMD_HIP(hipMemcpy(st.data(), d_status, B, hipMemcpyDeviceToHost));
     int failed = 0;

@@ -72,7 +72,6 @@ struct HostPipe
     hipStream_t compute = nullptr, copy = nullptr;
     CopyPool *pool      = nullptr;
     size_t chunk_override = 0;  // test hook: ciphertexts per chunk (0 = automatic)
-    bool no_small         = false;  // set while a small batch is redone on the sequential path
 
     ~HostPipe();
     int init(int device);
