@@ -631,7 +631,7 @@ def test_magnitude_classes_through_every_path(env, n, npr):
 
 
 @pytest.mark.parametrize("n,npr,B", [(4096, 3, 1), (4096, 3, 5), (4096, 2, 16), (8192, 6, 2), (16384, 6, 1),
-                                       (16384, 3, 2)])
+                                       (16384, 3, 2), (16384, 13, 1)])
 def test_small_batch_prime_speculation(env, n, npr, B):
     """Host-pointer calls with a handful of ciphertexts run every prime's uniform sampler at once
     under guessed start counters (k_spec_*, Context::encrypt_sym_small) and then follow the true
