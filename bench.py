@@ -5,17 +5,26 @@
   (N > 1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE env)
 
 A "step" is one pass of the hot path over one batch of synthetic plaintexts that are already
-resident in HBM.  Default workload = BASELINE config 2: n=4096, 3x30-bit primes, symmetric,
+resident in HBM.  Top-level workload = BASELINE config 2: n=4096, 3x30-bit primes, symmetric,
 batch 65536 PER GPU (weak scaling: every rank encrypts its own contiguous block of the batch
 index; no data-path collective).  Prints ONE JSON line on rank 0.
 
-Extra objects in the line:
-  roofline     -- dominant kernel: algorithmic bytes per launch / its HIP-event-measured average
-                  duration, against the 8 TB/s HBM peak (MI355X_MICROARCH.md).
-  cpu_baseline -- the reference's CPU path (oracle/_ref, kind "reference") or our C restatement
-                  (kind "port") timed on this box's host cores on a bounded sample (rank 0, N=1).
+Objects in the line beside the driver's contract fields:
+  roofline      -- bound "hbm": achieved = algorithmic bytes per step / measured step time against the
+                   8 TB/s HBM peak; `kernels` lists every kernel of the step with ITS OWN algorithmic
+                   bytes, its HIP-event-measured duration and its PMC-measured HBM traffic (null when
+                   profiles/pmc_traffic.json was collected for other kernel sources); `valu` is the
+                   operative second bound (VALU issue) from the SQ counters of profiles/sq_counters.json.
+  cpu_baseline  -- the reference's CPU path (oracle/_ref, kind "reference") or our C restatement (kind
+                   "port") timed on this box's host cores over a bounded sample (rank 0).
+  other_configs -- the remaining single-GPU BASELINE configs (C3, C4 at its per-GPU batch, C5 at 1 M,
+                   C1), each with its own roofline and cpu_baseline, measured in the same run (N = 1);
+                   for N > 1 the sharded C4 only.
+  gather        -- N > 1: the final gather of ciphertext records to rank 0 timed separately
+                   (`value_with_gather` = throughput with that time included).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,17 +35,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+VALU_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; a wave64 VALU instruction holds its SIMD 4 cycles
 
 WORKLOADS = {
-    # name: (n, nprimes, mode, default batch per GPU, algorithmic bytes per unit)
-    # bytes per unit: sym = 2n + 128 + 8*n*np; asym = 2n + 64 + 8*n*np;
-    # encode-only = 2n + 4*n*np
-    "c1": (1024, 1, "sym", 1, 2 * 1024 + 128 + 8 * 1024 * 1),
-    "c2": (4096, 3, "sym", 65536, 2 * 4096 + 128 + 8 * 4096 * 3),
-    "c3": (4096, 3, "asym", 65536, 2 * 4096 + 64 + 8 * 4096 * 3),
-    "c4": (16384, 6, "sym", 32768, 2 * 16384 + 128 + 8 * 16384 * 6),
-    "c5": (4096, 3, "encode", 262144, 2 * 4096 + 4 * 4096 * 3),
+    # name: (n, nprimes, mode, default batch per GPU)
+    "c1": (1024, 1, "sym", 1),
+    "c2": (4096, 3, "sym", 65536),
+    "c3": (4096, 3, "asym", 65536),
+    "c4": (16384, 6, "sym", 32768),
+    "c5": (4096, 3, "encode", 1048576),
 }
 DESCR = {
     "c1": "C1: n=1024, 1x27-bit prime, symmetric encode+encrypt",
@@ -45,11 +53,68 @@ DESCR = {
     "c4": "C4: n=16384, 6x30-bit RNS primes, symmetric encode+encrypt",
     "c5": "C5: n=4096, 3x30-bit RNS primes, encode-only (IFFT + RNS reduce + NTT)",
 }
+KERNEL_NAMES = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform", "ternary": "k_sample_ternary",
+                "encode_encrypt": "k_encode_encrypt", "encode_rns": "k_encode_rns", "ntt_fuse": "k_ntt_fuse"}
+
+
+def bytes_per_unit(mode, n, npr):
+    """Algorithmic bytes per unit (SURVEY.md 8(d)): sym = 2n + 128 + 8 n np; asym = 2n + 64 + 8 n np;
+    encode-only = 2n + 4 n np."""
+    if mode == "sym":
+        return 2 * n + 128 + 8 * n * npr
+    if mode == "asym":
+        return 2 * n + 64 + 8 * n * npr
+    return 2 * n + 4 * n * npr
+
+
+def kernel_bytes_per_unit(mode, n, npr):
+    """Each kernel's OWN algorithmic bytes per unit (what it must read + write given its inputs and
+    outputs in HBM)."""
+    poly = 4 * n * npr
+    if mode == "sym":
+        return {"uniform": 64 + poly,                   # seed in, a out
+                "cbd": 64 + n,                          # seed in, int8 error out
+                "encode_encrypt": 2 * n + n + poly + poly,   # values, e, a in; c0 out
+                "encode_rns": 2 * n + n + poly,         # values, e in; residues out
+                "ntt_fuse": poly + poly + poly}         # residues, a in; c0 out
+    if mode == "asym":
+        return {"ternary": 64 + n + 8,                  # seed in; codes + counter out
+                "cbd": 64 + 8 + 2 * n,                  # seed, counter in; e0 | e1 out
+                "encode_encrypt": 2 * n + n + 2 * n + 2 * poly}   # values, u, e0|e1 in; c0, c1 out
+    return {"encode_encrypt": 2 * n + poly}
+
+
+def kernel_source_hash():
+    """SHA-256 over the kernel sources: profiles collected for other sources are not quoted."""
+    h = hashlib.sha256()
+    kdir = os.path.join(ROOT, "seal-embedded_amd", "csrc", "kernels")
+    for name in sorted(os.listdir(kdir)):
+        if name.endswith((".hip", ".cuh", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(kdir, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "seal-embedded_amd", "csrc", "se_types.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(fname, workload, batch, src_hash):
+    """Per-kernel counters of `workload` from profiles/<fname>, or {} when they were collected for
+    other kernel sources / another batch."""
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+        ent = tj.get(workload)
+        if not ent or tj.get("_source_sha256", {}).get(workload) != src_hash:
+            return {}
+        return {k: v for k, v in ent.items() if isinstance(v, dict) and v.get("batch") == batch}
+    except Exception:
+        return {}
 
 
 def bench_values_device(B, n, dev, seed=0xC0FFEE, first=0):
-    """tests/vectors.py::bench_values evaluated on the GPU (same splitmix64 counter generator,
+    """tests/vectors.py::bench_values evaluated on the device (same splitmix64 counter generator,
     int64 arithmetic wraps like uint64); checked against the numpy version on the first rows."""
+    import numpy as np
     import torch
     import vectors as V
 
@@ -59,7 +124,6 @@ def bench_values_device(B, n, dev, seed=0xC0FFEE, first=0):
     def lsr(z, k):
         return (z >> k) & ((1 << (64 - k)) - 1)
 
-    import numpy as np
     # byte -> float through a table built by numpy (GPU float division need not be correctly rounded)
     table = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(-10.0)).to(dev)
     out = torch.empty((B, n // 2), dtype=torch.float32, device=dev)
@@ -79,125 +143,154 @@ def bench_values_device(B, n, dev, seed=0xC0FFEE, first=0):
     return out
 
 
-def cpu_baseline(n, npr, mode, budget_s=12.0):
+def cpu_baseline(n, npr, mode, budget_s=10.0):
     """Reference CPU path on this box's host cores over a bounded sample of the same workload
-    (region = encode + sampler init + per-prime encrypt, keys resident; bench_sym.c:96-130)."""
-    import numpy as np
+    (region = encode + sampler init + per-prime encrypt, keys resident; bench_sym.c:96-130,
+    bench_asym.c; encode-only: ckks_encode_base + per prime reduce_set_pte + ntt_inpl)."""
     import vectors as V
     from oracle import pyoracle
-    # host threads we may really use: affinity mask, clipped by the cgroup CPU quota if one is set
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            cores = max(1, min(cores, -(-int(quota) // int(period))))
-    except Exception:
-        pass
+    cores = pyoracle.host_threads()
     sk = V.secret_key(n)
     use_ref = pyoracle.ref_available()
-    kind = "reference" if use_ref else "port"
-    if mode != "sym":
-        use_ref, kind = False, "port"   # batched reference driver exists for the symmetric path
+    o = pyoracle.Oracle(n, npr)
+    pk = o.gen_pk(sk, bytes(64), bytes(range(64))) if mode == "asym" else None
+    R = pyoracle.Reference
 
-    def run(B, nthreads=None):
-        nthreads = nthreads or cores
+    def run(B, nthreads):
         vals = V.bench_values(B, n)
         ss, sd = V.bench_seeds(B)
         t0 = time.perf_counter()
         if mode == "sym":
             if use_ref:
-                pyoracle.Reference.encrypt_sym_batch(n, npr, vals, ss, sd, sk, nthreads=nthreads,
-                                                     keep=False)
+                R.encrypt_sym_batch(n, npr, vals, ss, sd, sk, nthreads=nthreads, keep=False)
             else:
-                pyoracle.Oracle(n, npr).encrypt_sym_batch(vals, ss, sd, sk, nthreads=nthreads,
-                                                          keep=False)
+                o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=nthreads, keep=False)
+        elif mode == "asym":
+            if use_ref:
+                R.encrypt_asym_batch(n, npr, vals, sd, pk[0], pk[1], nthreads=nthreads, keep=False)
+            else:
+                o.encrypt_asym_batch(vals, sd, pk[0], pk[1], nthreads=nthreads, keep=False)
         else:
-            o = pyoracle.Oracle(n, npr)
-            if mode == "asym":
-                pk0, pk1 = o.gen_pk(sk, bytes(64), bytes(range(64)))
-                for b in range(B):
-                    o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+            if use_ref:
+                R.encode_ntt_batch(n, npr, vals, nthreads=nthreads, keep=False)
             else:
-                for b in range(B):
-                    ok, m = o.encode(vals[b])
-                    for j in range(npr):
-                        o.ntt(o.reduce_pte(m, j), j)
+                o.encode_ntt_batch(vals, nthreads=nthreads, keep=False)
         return time.perf_counter() - t0
 
-    threads = cores if mode == "sym" else 1
-    probe = max(threads * 4, 8)
-    t = run(probe)
+    probe = max(cores * 2, 8)
+    run(min(probe, 8), cores)                      # warm: twiddle tables, page-in
+    t = run(probe, cores)
     B = int(max(probe, min(200000, probe * budget_s / max(t, 1e-6))))
-    B = max(threads, (B // threads) * threads)
-    t = run(B)
-    one = None
-    if mode == "sym":
-        b1 = max(8, int(2.0 * B / t / threads))      # ~2 s on one thread
-        one = b1 / run(b1, nthreads=1)
+    B = max(cores, (B // cores) * cores)
+    t = run(B, cores)
+    b1 = max(4, int(min(1.5, budget_s / 4) * B / t / cores))      # ~1.5 s on one thread
+    one = b1 / run(b1, 1)
+    src = ("oracle/_ref (the compiled reference, -O3 -fno-strict-aliasing)" if use_ref
+           else "oracle/se_oracle.c (C restatement, -O2)")
     return {"value": B / t, "unit": "ciphertexts/s" if mode != "encode" else "plaintexts/s",
-            "cores": threads, "kind": kind,
-            "sample": f"{B} units of the same synthetic workload in {t:.2f} s on {threads} host "
-                      f"thread(s); {'oracle/_ref (compiled reference, -O3 -fno-strict-aliasing)' if use_ref else 'oracle/se_oracle.c (C restatement, -O2)'}",
+            "cores": cores, "kind": "reference" if use_ref else "port",
+            "sample": f"{B} units of the same synthetic workload in {t:.2f} s on {cores} host thread(s); {src}",
             "single_thread_value": one}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="batch per GPU (0 = workload default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="also time the final RCCL gather of ciphertext records to rank 0")
-    args = ap.parse_args()
+class Backend:
+    """Device plumbing.  Normal mode: cuda + RCCL.  SE_BENCH_STUB=<module> (tests only): CPU tensors,
+    gloo, and the named module's Context standing in for the library, to exercise the rank logic."""
 
+    def __init__(self, local_rank):
+        import torch
+        self.torch = torch
+        self.stub = os.environ.get("SE_BENCH_STUB")
+        if self.stub:
+            import importlib
+            import __graft_entry__ as ge
+            ge.load_package()                      # seal_embedded_amd.sharding (pure Python) must be importable
+            self.mod = importlib.import_module(self.stub)
+            self.dev = torch.device("cpu")
+            self.dist_backend = "gloo"
+            self.num_cus = 256
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+            torch.cuda.set_device(local_rank)
+            self.dev = torch.device("cuda", local_rank)
+            self.dist_backend = "nccl"
+            import __graft_entry__ as ge
+            ge.ensure_built()
+            self.mod = ge.load_package()
+            self.num_cus = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
+        self.local_rank = local_rank
+
+    def sync(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def free_bytes(self):
+        if self.stub:
+            return 1 << 40
+        self.torch.cuda.empty_cache()
+        return self.torch.cuda.mem_get_info()[0]
+
+    def values(self, B, n, first):
+        if self.stub:
+            import vectors as V
+            return self.torch.from_numpy(V.bench_values(B, n, first=first))
+        return bench_values_device(B, n, self.dev, first=first)
+
+
+def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budget, want_gather, src_hash):
+    """One workload: timed region per the driver's contract, per-kernel profile, optional gather."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
     import vectors as V
-    import __graft_entry__ as ge
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # under torch.distributed.run (RANK/MASTER_PORT set) always bring RCCL up, also for one rank
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    n, npr, mode, defB, bytes_per_unit = WORKLOADS[args.workload]
-    B = args.batch or defB
-    ge.ensure_built()
-    pkg = ge.load_package()
-    ctx = pkg.Context(n, npr, local_rank)
+    torch = be.torch
+    n, npr, mode, _ = WORKLOADS[name]
+    use_dist = dist is not None
+    bpu = bytes_per_unit(mode, n, npr)
+    ctx = be.mod.Context(n, npr, be.local_rank)
     sk = V.secret_key(n)
     if mode == "sym":
         ctx.set_secret_key(sk)
     elif mode == "asym":
-        # public key from fixed seeds: gen_pk on the GPU (se_amd_gen_public_key)
-        pk0, pk1 = ctx.gen_public_key(sk, bytes(64), bytes(range(64)))
+        pk0, pk1 = ctx.gen_public_key(sk, bytes(64), bytes(range(64)))   # fixed seeds, gen_pk on the GPU
         ctx.set_public_key(pk0, pk1)
 
     # ---- synthetic inputs, resident in HBM before timing; rank r owns batch block r ----------
     first = rank * B
-    vals = bench_values_device(B, n, dev, first=first)
-    ss_np, sd_np = V.bench_seeds(B, first=first)
-    ss, sd = torch.from_numpy(ss_np).to(dev), torch.from_numpy(sd_np).to(dev)
-    c0 = torch.empty((B, npr, n), dtype=torch.int32, device=dev)
-    c1 = torch.empty((B, npr, n), dtype=torch.int32, device=dev) if mode != "encode" else None
-    status = torch.zeros(B, dtype=torch.uint8, device=dev)
+    vals = be.values(B, n, first)
+    ss_np, sd_np = V.bench_seeds(B, first=first) if mode != "encode" else (np.zeros((B, 64), np.uint8),) * 2
+    ss, sd = torch.from_numpy(ss_np).to(be.dev), torch.from_numpy(sd_np).to(be.dev)
+    rec = (npr, n)
+    rec_bytes = 4 * npr * n
+    # The root of a gathered run produces its block in place inside the gathered slab.
+    gather_plan = None
+    c0_all = c1_all = None
+    if want_gather and use_dist and world > 1:
+        slabs = 1 if mode == "encode" else 2
+        need_full = world * B * rec_bytes * slabs
+        need_local = B * rec_bytes * slabs
+        free = be.free_bytes()
+        margin = 6 << 30
+        if rank != 0 or free > need_full + margin:
+            gather_plan = "full"
+        elif mode == "sym" and free > world * B * rec_bytes + B * rec_bytes + margin:
+            gather_plan = "seed-compressed"        # c0 + 64-byte shareable seeds; c1 = expand(seed)
+        flag = torch.tensor([0 if gather_plan is None else (1 if gather_plan == "full" else 2)],
+                            dtype=torch.int64, device=be.dev)
+        dist.broadcast(flag, src=0)                 # the root decides for everybody
+        gather_plan = {0: None, 1: "full", 2: "seed-compressed"}[int(flag.item())]
+        del need_local
+    if gather_plan and rank == 0:
+        c0_all = torch.empty((world * B,) + rec, dtype=torch.int32, device=be.dev)
+        c0 = c0_all[:B]
+        if mode != "encode" and gather_plan == "full":
+            c1_all = torch.empty((world * B,) + rec, dtype=torch.int32, device=be.dev)
+            c1 = c1_all[:B]
+        else:
+            c1 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev) if mode != "encode" else None
+    else:
+        c0 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev)
+        c1 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev) if mode != "encode" else None
+    status = torch.zeros(B, dtype=torch.uint8, device=be.dev)
 
     def step():
         if mode == "sym":
@@ -208,110 +301,180 @@ def main():
             ctx.encode_ntt(vals, c0, status=status)
 
     def fence():
-        torch.cuda.synchronize()
+        be.sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.sync()
 
     ctx.reserve(B)  # scratch allocation is not a step
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=be.dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if not os.environ.get("SE_BENCH_SKIP_STATUS"):   # timing-only ablation builds produce garbage
         assert bool(status.all()), "an encode overflowed on synthetic data"
+    ms_per_step = elapsed / steps * 1e3
 
-    # ---- per-kernel durations with HIP events on the launch stream (separate profiled run) ---
+    # ---- per-kernel durations with HIP events on the launch stream (separate profiled steps) ---
     ctx.set_profiling(True)
     ctx.stage_ms(reset=True)
-    prof_steps = min(args.steps, 5)
+    prof_steps = max(1, min(steps, 5))
     for _ in range(prof_steps):
         step()
-    torch.cuda.synchronize()
+    be.sync()
     stages = ctx.stage_ms(reset=True)
     ctx.set_profiling(False)
-    # A kernel may be launched several times per step (the symmetric pipeline runs the uniform
-    # sampler and the NTT kernel once per prime); all launches of one step together process the B
-    # units of the step, so they are accounted as one logical launch: duration = sum over the
-    # step's launches, algorithmic bytes = bytes_per_unit x B.
-    per_step = {s: ms / prof_steps for s, (ms, cnt) in stages.items()}
-    launches = {s: cnt / prof_steps for s, (ms, cnt) in stages.items()}
-    # The dominant kernel is the longest one ON THE MAIN STREAM (the critical path).  The CBD sampler
-    # of the symmetric pipeline runs on the auxiliary stream beside the uniform sampler; its elapsed
-    # time is stretched by the co-runner (1.7 ms alone, 5-6.5 ms beside it) and says nothing about the
-    # step, so it is never picked there.
-    hidden = {"cbd"} if mode == "sym" else set()
-    dominant = max((s for s in per_step if s not in hidden), key=per_step.get)
-    dom_ms = per_step[dominant]
-    kernel_names = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform",
-                    "ternary": "k_sample_ternary", "encode_encrypt": "k_encode_encrypt",
-                    "encode_rns": "k_encode_rns", "ntt_fuse": "k_ntt_fuse"}
-    achieved = bytes_per_unit * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # A kernel may be launched several times per step (the per-prime pipeline runs the uniform sampler
+    # and the NTT kernel once per prime); the launches of one step together process the step's B units:
+    # duration = their sum, algorithmic bytes = that kernel's bytes per unit x B.
+    kbytes = kernel_bytes_per_unit(mode, n, npr)
+    pmc = load_profile("pmc_traffic.json", name, B, src_hash)
+    sq = load_profile("sq_counters.json", name, B, src_hash)
+    kernels = []
+    for s, (ms, cnt) in stages.items():
+        if ms <= 0 or cnt == 0:
+            continue
+        kms = ms / prof_steps
+        alg = kbytes.get(s, 0) * B
+        ent = pmc.get(KERNEL_NAMES[s])
+        kernels.append({"kernel": KERNEL_NAMES[s], "ms_per_step": kms, "launches_per_step": cnt / prof_steps,
+                        "algorithmic_bytes": alg, "achieved": alg / (kms * 1e-3) / 1e9,
+                        "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": ent["hbm_bytes_per_step"] if ent else None})
+    # The dominant kernel is the longest one ON THE MAIN STREAM (the critical path).  The CBD sampler of
+    # the symmetric pipeline runs on the auxiliary stream beside the uniform sampler: its elapsed time is
+    # stretched by the co-runner and says nothing about the step.
+    hidden = {"k_sample_cbd"} if mode == "sym" else set()
+    main = [k for k in kernels if k["kernel"] not in hidden]
+    dom = max(main, key=lambda k: k["ms_per_step"]) if main else None
+    achieved = bpu * B / (ms_per_step * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            ent = tj.get(args.workload, {}).get(kernel_names[dominant])
-            if ent and ent.get("batch") == B:
-                traffic = ent["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    if pmc and all(KERNEL_NAMES[s] in pmc for s, (ms, cnt) in stages.items() if cnt):
+        traffic = sum(pmc[KERNEL_NAMES[s]]["hbm_bytes_per_step"] for s, (ms, cnt) in stages.items() if cnt)
+    valu = None
+    if sq and all(KERNEL_NAMES[s] in sq for s, (ms, cnt) in stages.items() if cnt):
+        insts = sum(sq[KERNEL_NAMES[s]]["valu_wave_insts_per_step"] for s, (ms, cnt) in stages.items() if cnt)
+        simds = 4 * be.num_cus
+        floor_ms = insts * 4.0 / simds / VALU_CLOCK_HZ * 1e3
+        valu = {"bound": "valu", "wave_insts_per_step": insts, "simds": simds, "clock_hz": VALU_CLOCK_HZ,
+                "floor_ms": floor_ms, "frac": floor_ms / ms_per_step,
+                "note": "wave64 VALU instruction = 4 SIMD cycles; floor = insts x 4 / SIMDs / clock"}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": kernel_names[dominant], "kernel_ms": dom_ms,
-                "launches_per_step": launches[dominant],
-                "algorithmic_bytes_per_launch": bytes_per_unit * B,
-                "stage_ms_per_step": {k: v for k, v in per_step.items() if v > 0},
-                "pipeline_frac": bytes_per_unit * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
+                "scope": "whole step: bytes_per_unit x batch / ms_per_step",
+                "algorithmic_bytes_per_step": bpu * B,
+                "dominant_kernel": dom, "kernels": kernels, "valu": valu,
+                "profile_source_sha256": src_hash}
 
     gather = None
-    if args.gather and use_dist and mode != "encode":
+    if gather_plan:
         from seal_embedded_amd.sharding import gather_records
+        sizes = [B] * world
         fence()
         g0 = time.perf_counter()
-        for slab in (c0, c1):
-            gather_records(slab, dist, dst=0, chunk_records=4096)
+        gather_records(c0, dist, dst=0, out=c0_all, sizes=sizes)
+        moved = (world - 1) * B * rec_bytes
+        if gather_plan == "full" and c1 is not None:
+            gather_records(c1, dist, dst=0, out=c1_all, sizes=sizes)
+            moved *= 2
+        elif gather_plan == "seed-compressed":
+            gather_records(ss, dist, dst=0, sizes=sizes)
+            moved += (world - 1) * B * 64
         fence()
         gsec = time.perf_counter() - g0
-        gather = {"ms": gsec * 1e3, "bytes_into_root": 2 * (world - 1) * c0.numel() * 4,
-                  "GB/s": 2 * (world - 1) * c0.numel() * 4 / gsec / 1e9}
+        tg = torch.tensor([gsec], dtype=torch.float64, device=be.dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gsec = float(tg.item())
+        if rank == 0 and os.environ.get("SE_BENCH_DUMP") and gather_plan == "full" and c1_all is not None:
+            import numpy as _np                    # test hook: the gathered slabs, rank order
+            _np.savez(os.environ["SE_BENCH_DUMP"], c0=c0_all.cpu().numpy(), c1=c1_all.cpu().numpy())
+        gather = {"form": gather_plan, "ms": gsec * 1e3, "bytes_into_root": moved, "GB/s": moved / gsec / 1e9,
+                  "value_with_gather": world * B / (ms_per_step * 1e-3 + gsec),
+                  "method": "batch_isend_irecv: every rank writes its block into its slice of the root's slab"}
+    elif want_gather and use_dist and world > 1:
+        gather = {"form": None, "skipped": "not enough free HBM on the root for the gathered slab"}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(n, npr, mode)
+    cpu = cpu_baseline(n, npr, mode, cpu_budget) if (want_cpu and rank == 0) else None
+    unit = "ciphertexts/s" if mode != "encode" else "plaintexts/s"
+    res = {
+        "metric": "CKKS ciphertexts/s (batched encode+encrypt)" if mode != "encode"
+                  else "CKKS plaintexts/s (batched encode + RNS NTT)",
+        "value": world * B * steps / elapsed, "unit": unit, "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": DESCR[name] + f", batch={B} per GPU", "n": n, "nprimes": npr, "mode": mode,
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}",
+                   "bytes_per_unit": bpu},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if gather:
+        res["gather"] = gather
+    if hasattr(ctx, "close"):
+        ctx.close()
+    del vals, ss, sd, c0, c1, c0_all, c1_all, status
+    if not be.stub:
+        torch.cuda.empty_cache()
+    return res
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="batch per GPU (0 = workload default)")
+    ap.add_argument("--others", default=None,
+                    help="comma list of further workloads reported under other_configs "
+                         "(default: c3,c4,c5,c1 at N=1, c4 at N>1 when the main workload is c2; 'none')")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the timed final gather")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
+    be = Backend(local_rank)
+    # under torch.distributed.run (RANK/MASTER_PORT set) always bring the process group up, also for one rank
+    dist = None
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if be.stub:
+            dist.init_process_group(be.dist_backend)
+        else:
+            dist.init_process_group(be.dist_backend, device_id=be.dev)
+
+    src_hash = kernel_source_hash()
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    want_gather = world > 1 and not args.no_gather
+    B = args.batch or WORKLOADS[args.workload][3]
+    line = run_config(be, dist, args.workload, B, args.steps, args.warmup, rank, world, want_cpu, 10.0,
+                      want_gather, src_hash)
+    if args.others is None:
+        others = [] if args.workload != "c2" or args.batch else (["c3", "c4", "c5", "c1"] if world == 1 else ["c4"])
+    else:
+        others = [w for w in args.others.split(",") if w and w != "none"]
+    extra = []
+    for w in others:
+        k = max(2, min(args.steps, 5))
+        extra.append(run_config(be, dist, w, WORKLOADS[w][3], k, min(args.warmup, 1) or 1, rank, world, want_cpu,
+                                4.0, want_gather, src_hash))
+    if extra:
+        line["other_configs"] = extra
     if rank == 0:
-        units = world * B * args.steps
-        line = {
-            "metric": "CKKS ciphertexts/s (batched encode+encrypt)" if mode != "encode"
-                      else "CKKS plaintexts/s (batched encode + RNS NTT)",
-            "value": units / elapsed,
-            "unit": "ciphertexts/s" if mode != "encode" else "plaintexts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": DESCR[args.workload] + f", batch={B} per GPU", "n": n,
-                       "nprimes": npr, "mode": mode, "batch_per_gpu": B,
-                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}",
-                       "bytes_per_unit": bytes_per_unit},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        if gather:
-            line["gather"] = gather
         print(json.dumps(line), flush=True)
-    if use_dist:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

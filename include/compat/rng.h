@@ -1,0 +1,7 @@
+/* rng.h -- shim under the reference's header name (device/lib/rng.h): callers written against
+ * SEAL-Embedded's own headers compile unchanged against libseal_embedded_amd.so.  Everything is
+ * declared in seal_embedded_amd.h / seal_embedded_amd_lower.h. */
+#ifndef SEAMD_SHIM_RNG_H
+#define SEAMD_SHIM_RNG_H
+#include "../seal_embedded_amd.h"
+#endif

@@ -32,6 +32,15 @@
 #include <stdint.h>
 #include <sys/types.h>
 
+/* complex128 as the reference spells it (`double complex`, ckks_common.h:38); C++ translation
+ * units see the same type through the GNU `_Complex` keyword */
+#ifdef __cplusplus
+typedef double _Complex se_complex;
+#else
+#include <complex.h>
+typedef double complex se_complex;
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -77,17 +86,17 @@ typedef struct
 
 typedef struct SE_PTRS
 {
-    double *conj_vals;  /* n complex128 (re,im interleaved); first 8n bytes hold int64 plaintext */
-    double *ifft_roots; /* unused (roots live on the device) */
-    flpt *values;       /* n/2 floats */
-    ZZ *ternary;        /* 2-bit packed s (sym) / u (asym), n/4 bytes */
+    se_complex *conj_vals;  /* n complex128; first 8n bytes hold the int64 plaintext after encode */
+    se_complex *ifft_roots; /* 0, as in the reference's default SE_IFFT_OTF (ckks_sym.c:91) */
+    flpt *values;           /* n/2 floats */
+    ZZ *ternary;            /* 2-bit packed s (sym) / u of the last call (asym), n/4 bytes */
     int64_t *conj_vals_int_ptr;
-    ZZ *c0_ptr; /* n residues of the current prime (host staging buffer) */
+    ZZ *c0_ptr; /* n residues of the current prime */
     ZZ *c1_ptr;
     uint16_t *index_map_ptr;
-    ZZ *ntt_roots_ptr; /* unused (tables live on the device) */
+    ZZ *ntt_roots_ptr; /* one-shot NTT roots of the last prime processed (ntt.c:40-52) */
     ZZ *ntt_pte_ptr;
-    int8_t *e1_ptr;
+    int8_t *e1_ptr; /* e1 of the last asymmetric call */
 } SE_PTRS;
 
 typedef struct
@@ -98,6 +107,7 @@ typedef struct
 
 typedef enum { SE_SYM_ENCR, SE_ASYM_ENCR } EncryptType;
 typedef size_t (*SEND_FNCT_PTR)(void *, size_t);
+typedef ssize_t (*RND_FNCT_PTR)(void *, size_t, unsigned int flags); /* seal_embedded.h:73 */
 
 /* ---- layer 1: the reference API (seal_embedded.h:91-130) ----------------------------------
  * Behaviour kept: default parameter sets only (custom moduli are unreachable in the reference,
@@ -226,6 +236,15 @@ int se_amd_sample_ternary_device(se_amd_ctx *ctx, const uint8_t *d_seeds, size_t
 int se_amd_sample_cbd_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const uint64_t *d_ctr_base,
                              size_t B, size_t blocks_per_ct, int8_t *d_out, void *stream);
 void se_amd_pack_ternary_host(const int8_t *codes, size_t n, uint8_t *packed /*[n/4]*/);
+/* Known-answer access to the device word arithmetic the kernels are built from (modulo.h:21-116,
+ * uintmodarith.h:26-346 as restated in kernels/modarith.cuh), element-wise for prime j:
+ * op 0 barrett 32->32 (a), 1 barrett 64->32 (a), 2 mul_mod(a, b) by 64-bit Barrett, 3 mul_mod(a, b) by
+ * the Shoup form, 4 add_mod, 5 neg_mod(a), 6 sub_mod, 7 signed reduction of (int64)a
+ * (ckks_common.c:224-237), 8 canonicalisation of a < 4q, 9/10 the two outputs of the Harvey NTT
+ * butterfly on (a, b) with root c (ntt.c:156-162), 11/12 of the Gentleman-Sande butterfly
+ * (intt.c:188-195).  Operands are uint64 arrays (b, c may be NULL where unused). */
+int se_amd_word_ops_device(se_amd_ctx *ctx, size_t prime, int op, const uint64_t *d_a, const uint64_t *d_b,
+                           const uint64_t *d_c, uint32_t *d_out, size_t count, void *stream);
 
 /* ---- formats on either side of the path (host only) ---------------------------------------- */
 /* SEAL Ciphertext data of size 2 (adapter/fileops.cpp:515-527): out[i + j*n] = c0 prime j,
@@ -295,4 +314,9 @@ const char *se_amd_version(void);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- layer 1b: the reference's lower surface under its own names (ckks_encode_base, ckks_setup,
+ *      ckks_sym_init, ckks_encode_encrypt_sym, gen_pk, ntt_inpl, ifft_inpl, ...) ---------------- */
+#include "seal_embedded_amd_lower.h"
+
 #endif /* SEAL_EMBEDDED_AMD_H */

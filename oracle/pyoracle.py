@@ -107,6 +107,11 @@ class Oracle:
             L.seo_encrypt_sym_batch.restype = C.c_int
             L.seo_encrypt_sym_batch.argtypes = [C.POINTER(SeoParams), f32p, C.c_size_t, u8p, u8p,
                                                 u8p, u32p, u32p, C.c_int]
+            L.seo_encrypt_asym_batch.restype = C.c_int
+            L.seo_encrypt_asym_batch.argtypes = [C.POINTER(SeoParams), f32p, C.c_size_t, u8p, u32p, u32p,
+                                                 u32p, u32p, C.c_int]
+            L.seo_encode_ntt_batch.restype = C.c_int
+            L.seo_encode_ntt_batch.argtypes = [C.POINTER(SeoParams), f32p, C.c_size_t, u32p, C.c_int]
             L.seo_fnv1a64.restype = C.c_uint64
             L.seo_fnv1a64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
             cls._lib = L
@@ -318,6 +323,41 @@ class Oracle:
         return bool(ok), c0, c1
 
 
+    def encrypt_asym_batch(self, values, seeds, pk0, pk1, nthreads=1, keep=True):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        B = v.shape[0]
+        sd = np.ascontiguousarray(seeds, dtype=np.uint8)
+        pk0 = np.ascontiguousarray(pk0, dtype=np.uint32)
+        pk1 = np.ascontiguousarray(pk1, dtype=np.uint32)
+        c0 = np.zeros((B, self.np, self.n), dtype=np.uint32) if keep else None
+        c1 = np.zeros((B, self.np, self.n), dtype=np.uint32) if keep else None
+        ok = self.L.seo_encrypt_asym_batch(C.byref(self.p), _p(v, f32p), B, _p(sd, u8p), _p(pk0, u32p),
+                                           _p(pk1, u32p), _p(c0, u32p), _p(c1, u32p), nthreads)
+        return bool(ok), c0, c1
+
+    def encode_ntt_batch(self, values, nthreads=1, keep=True):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        B = v.shape[0]
+        out = np.zeros((B, self.np, self.n), dtype=np.uint32) if keep else None
+        ok = self.L.seo_encode_ntt_batch(C.byref(self.p), _p(v, f32p), B, _p(out, u32p), nthreads)
+        return bool(ok), out
+
+
+def host_threads():
+    """Host threads this process may really use: affinity mask clipped by the cgroup CPU quota."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def fnv1a64(data, h=0):
     L = Oracle.lib()
     b = np.frombuffer(bytes(data), dtype=np.uint8)
@@ -383,6 +423,11 @@ class Reference:
             L.refh_decrypt.argtypes = [C.c_void_p, C.c_size_t, u32p, u32p, u32p, u32p]
             L.refh_decode.argtypes = [C.c_void_p, C.c_size_t, u32p, C.c_size_t, f32p]
             L.refh_print_to_file.argtypes = [C.c_char_p, C.c_char_p, u32p, C.c_size_t, f32p, C.c_size_t]
+            L.refh_encrypt_asym_batch.restype = C.c_int
+            L.refh_encrypt_asym_batch.argtypes = [C.c_size_t, C.c_size_t, f32p, C.c_size_t, u8p, u32p,
+                                                  u32p, u32p, u32p, C.c_int]
+            L.refh_encode_ntt_batch.restype = C.c_int
+            L.refh_encode_ntt_batch.argtypes = [C.c_size_t, C.c_size_t, f32p, C.c_size_t, u32p, C.c_int]
             L.refh_encrypt_sym_batch.restype = C.c_int
             L.refh_encrypt_sym_batch.argtypes = [C.c_size_t, C.c_size_t, f32p, C.c_size_t, u8p,
                                                  u8p, u8p, u32p, u32p, C.c_int]
@@ -599,3 +644,26 @@ class Reference:
         L.refh_encrypt_sym_batch(n, nprimes, _p(v, f32p), B, _p(ss, u8p), _p(sd, u8p),
                                  _p(sk, u8p), _p(c0, u32p), _p(c1, u32p), nthreads)
         return c0, c1
+
+    @classmethod
+    def encrypt_asym_batch(cls, n, nprimes, values, seeds, pk0, pk1, nthreads=1, keep=True):
+        L = cls.lib()
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        B = v.shape[0]
+        sd = np.ascontiguousarray(seeds, dtype=np.uint8)
+        pk0 = np.ascontiguousarray(pk0, dtype=np.uint32)
+        pk1 = np.ascontiguousarray(pk1, dtype=np.uint32)
+        c0 = np.zeros((B, nprimes, n), dtype=np.uint32) if keep else None
+        c1 = np.zeros((B, nprimes, n), dtype=np.uint32) if keep else None
+        L.refh_encrypt_asym_batch(n, nprimes, _p(v, f32p), B, _p(sd, u8p), _p(pk0, u32p), _p(pk1, u32p),
+                                  _p(c0, u32p), _p(c1, u32p), nthreads)
+        return c0, c1
+
+    @classmethod
+    def encode_ntt_batch(cls, n, nprimes, values, nthreads=1, keep=True):
+        L = cls.lib()
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        B = v.shape[0]
+        out = np.zeros((B, nprimes, n), dtype=np.uint32) if keep else None
+        L.refh_encode_ntt_batch(n, nprimes, _p(v, f32p), B, _p(out, u32p), nthreads)
+        return out

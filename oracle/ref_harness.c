@@ -444,6 +444,85 @@ int refh_encrypt_sym_batch(size_t n, size_t nprimes, const float *values, size_t
     return 1;
 }
 
+/* --- the same for the public-key path (bench_asym.c region: encode + ckks_asym_init + per-prime
+ *     ckks_encode_encrypt_asym, pk resident in memory) and for encode-only (BASELINE config 5:
+ *     ckks_encode_base + per prime reduce_set_pte + ntt_inpl) ------------------------------------ */
+typedef struct
+{
+    size_t n, nprimes, lo, hi;
+    const float *values;
+    const uint8_t *seeds;
+    const uint32_t *pk0, *pk1;
+    uint32_t *c0, *c1;
+    refh *h;
+    int mode; /* 1 asym, 2 encode + ntt */
+} ref_job2;
+
+static void *ref_worker2(void *arg)
+{
+    ref_job2 *jb = (ref_job2 *)arg;
+    size_t n = jb->n, np = jb->nprimes;
+    uint32_t *s0 = (uint32_t *)malloc(np * n * 4), *s1 = (uint32_t *)malloc(np * n * 4);
+    for (size_t b = jb->lo; b < jb->hi; b++)
+    {
+        uint32_t *o0 = jb->c0 ? jb->c0 + b * np * n : s0;
+        uint32_t *o1 = jb->c1 ? jb->c1 + b * np * n : s1;
+        if (jb->mode == 1)
+            refh_encrypt_asym(jb->h, jb->values + b * (n / 2), n / 2, jb->seeds + 64 * b, jb->pk0, jb->pk1,
+                              o0, o1, NULL, NULL, NULL, NULL);
+        else
+        {
+            refh *h = jb->h;
+            ckks_reset_primes(&h->parms);
+            refh_encode(h, jb->values + b * (n / 2), n / 2, NULL);
+            for (size_t j = 0; j < np; j++)
+            {
+                reduce_set_pte(&h->parms, h->ptrs.conj_vals_int_ptr, o0 + j * n);
+                ntt_roots_initialize(&h->parms, h->ptrs.ntt_roots_ptr);
+                ntt_inpl(&h->parms, h->ptrs.ntt_roots_ptr, o0 + j * n);
+                if (j + 1 < np) next_modulus(&h->parms);
+            }
+        }
+    }
+    free(s0);
+    free(s1);
+    return NULL;
+}
+
+static int ref_batch2(size_t n, size_t nprimes, int mode, const float *values, size_t B,
+                      const uint8_t *seeds, const uint32_t *pk0, const uint32_t *pk1, uint32_t *c0,
+                      uint32_t *c1, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th  = (pthread_t *)malloc(nthreads * sizeof(pthread_t));
+    ref_job2 *jobs = (ref_job2 *)malloc(nthreads * sizeof(ref_job2));
+    for (int t = 0; t < nthreads; t++)
+    { /* instances are created serially: refh_open redirects stdout */
+        ref_job2 jb = {n, nprimes, B * t / nthreads, B * (t + 1) / nthreads, values, seeds, pk0, pk1,
+                       c0, c1, (refh *)refh_open(n, nprimes, mode == 1), mode};
+        jobs[t] = jb;
+    }
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, ref_worker2, &jobs[t]);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < nthreads; t++) refh_close(jobs[t].h);
+    free(th);
+    free(jobs);
+    return 1;
+}
+
+int refh_encrypt_asym_batch(size_t n, size_t nprimes, const float *values, size_t B, const uint8_t *seeds,
+                            const uint32_t *pk0, const uint32_t *pk1, uint32_t *c0, uint32_t *c1,
+                            int nthreads)
+{
+    return ref_batch2(n, nprimes, 1, values, B, seeds, pk0, pk1, c0, c1, nthreads);
+}
+
+int refh_encode_ntt_batch(size_t n, size_t nprimes, const float *values, size_t B, uint32_t *out,
+                          int nthreads)
+{
+    return ref_batch2(n, nprimes, 2, values, B, NULL, NULL, NULL, out, NULL, nthreads);
+}
+
 /* --- the reference's own text printers, captured into a file (format pin for se_formats.cpp) --- */
 void refh_print_to_file(const char *path, const char *name, const uint32_t *poly, size_t n,
                         const float *values, size_t vlen)

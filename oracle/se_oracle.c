@@ -828,6 +828,95 @@ int seo_encrypt_sym_batch(const seo_params *p, const float *values, size_t B,
     return ok;
 }
 
+/* Public-key and encode-only counterparts (BASELINE configs 3 and 5): same sharding.  Region per
+ * unit = bench_asym.c's (encode + ckks_asym_init + per-prime encrypt, pk resident) resp. encode +
+ * per-prime reduce_set_pte + ntt_inpl. */
+typedef struct
+{
+    const seo_params *p;
+    const uint16_t *map;
+    const float *values;
+    const uint8_t *seeds;
+    const uint32_t *pk0, *pk1;
+    uint32_t *c0, *c1;
+    size_t lo, hi;
+    int mode; /* 1 asym, 2 encode + ntt */
+    int ok;
+} seo_job2;
+
+static void *seo_worker2(void *arg)
+{
+    seo_job2 *jb  = (seo_job2 *)arg;
+    size_t n      = jb->p->n, np = jb->p->nprimes;
+    uint32_t *s0  = (uint32_t *)malloc(np * n * sizeof(uint32_t));
+    uint32_t *s1  = (uint32_t *)malloc(np * n * sizeof(uint32_t));
+    int64_t *m    = (int64_t *)malloc(n * sizeof(int64_t));
+    uint32_t *rts = (uint32_t *)malloc(np * n * sizeof(uint32_t));
+    for (size_t j = 0; j < np; j++) seo_ntt_roots(jb->p, j, rts + j * n);
+    jb->ok = 1;
+    for (size_t b = jb->lo; b < jb->hi; b++)
+    {
+        uint32_t *o0 = jb->c0 ? jb->c0 + b * np * n : s0;
+        uint32_t *o1 = jb->c1 ? jb->c1 + b * np * n : s1;
+        if (jb->mode == 1)
+            jb->ok &= seo_encrypt_asym(jb->p, jb->map, jb->values + b * (n / 2), n / 2, jb->seeds + 64 * b,
+                                       jb->pk0, jb->pk1, o0, o1, NULL, NULL, NULL, NULL);
+        else
+        {
+            jb->ok &= seo_encode(jb->p, jb->values + b * (n / 2), n / 2, jb->map, m);
+            for (size_t j = 0; j < np; j++)
+            {
+                seo_reduce_pte(jb->p, j, m, o0 + j * n);
+                seo_ntt_inpl(jb->p, j, rts + j * n, o0 + j * n);
+            }
+        }
+    }
+    free(s0);
+    free(s1);
+    free(m);
+    free(rts);
+    return NULL;
+}
+
+static int seo_batch2(const seo_params *p, int mode, const float *values, size_t B, const uint8_t *seeds,
+                      const uint32_t *pk0, const uint32_t *pk1, uint32_t *c0, uint32_t *c1, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    uint16_t *map = (uint16_t *)malloc(p->n * sizeof(uint16_t));
+    seo_index_map(p->n, p->logn, map);
+    (void)twiddles_for(p->n, p->logn);
+    pthread_t *th  = (pthread_t *)malloc(nthreads * sizeof(pthread_t));
+    seo_job2 *jobs = (seo_job2 *)malloc(nthreads * sizeof(seo_job2));
+    for (int t = 0; t < nthreads; t++)
+    {
+        seo_job2 jb = {p, map, values, seeds, pk0, pk1, c0, c1, B * t / nthreads, B * (t + 1) / nthreads, mode, 1};
+        jobs[t]     = jb;
+        pthread_create(&th[t], NULL, seo_worker2, &jobs[t]);
+    }
+    int ok = 1;
+    for (int t = 0; t < nthreads; t++)
+    {
+        pthread_join(th[t], NULL);
+        ok &= jobs[t].ok;
+    }
+    free(th);
+    free(jobs);
+    free(map);
+    return ok;
+}
+
+int seo_encrypt_asym_batch(const seo_params *p, const float *values, size_t B, const uint8_t *seeds,
+                           const uint32_t *pk0, const uint32_t *pk1, uint32_t *c0, uint32_t *c1,
+                           int nthreads)
+{
+    return seo_batch2(p, 1, values, B, seeds, pk0, pk1, c0, c1, nthreads);
+}
+
+int seo_encode_ntt_batch(const seo_params *p, const float *values, size_t B, uint32_t *out, int nthreads)
+{
+    return seo_batch2(p, 2, values, B, NULL, NULL, NULL, out, NULL, nthreads);
+}
+
 /* FNV-1a 64 (digests of callback byte streams) */
 uint64_t seo_fnv1a64(const void *data, size_t len, uint64_t h)
 {

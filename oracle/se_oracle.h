@@ -127,6 +127,14 @@ int seo_encrypt_sym_batch(const seo_params *p, const float *values /*[B][n/2]*/,
                           const uint8_t *sk_packed, uint32_t *c0 /*[B][np][n] or NULL*/,
                           uint32_t *c1 /*[B][np][n] or NULL*/, int nthreads);
 
+int seo_encrypt_asym_batch(const seo_params *p, const float *values /*[B][n/2]*/, size_t B,
+                           const uint8_t *seeds /*[B][64]*/, const uint32_t *pk0 /*[np][n]*/,
+                           const uint32_t *pk1, uint32_t *c0 /*[B][np][n] or NULL*/,
+                           uint32_t *c1 /*[B][np][n] or NULL*/, int nthreads);
+/* BASELINE config 5: out[b][j] = NTT_j(reduce_set_pte(encode(values[b]))) ([B][np][n] or NULL) */
+int seo_encode_ntt_batch(const seo_params *p, const float *values /*[B][n/2]*/, size_t B,
+                         uint32_t *out, int nthreads);
+
 uint64_t seo_fnv1a64(const void *data, size_t len, uint64_t h);
 
 #ifdef __cplusplus

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_encode_ntt_device", "se_amd_encrypt_sym_host", "se_amd_encrypt_asym_host",
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_intt_device", "se_amd_decrypt_decode_device", "se_amd_prng_blocks_device",
     "se_amd_sample_uniform_device", "se_amd_sample_ternary_device", "se_amd_sample_cbd_device",
-    "se_amd_pack_ternary_host", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
+    "se_amd_pack_ternary_host", "se_amd_word_ops_device", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
     "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
     "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
@@ -98,6 +98,7 @@ def lib():
     L.se_amd_sample_uniform_device.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     L.se_amd_sample_ternary_device.argtypes = [vp, vp, sz, vp, vp, vp]
     L.se_amd_sample_cbd_device.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+    L.se_amd_word_ops_device.argtypes = [vp, sz, i32, vp, vp, vp, vp, sz, vp]
     L.se_amd_pack_ternary_host.argtypes = [vp, sz, vp]
     L.se_amd_pack_ternary_host.restype = None
     L.se_amd_pack_seal_ciphertext_host.argtypes = [vp, vp, sz, sz, vp]
@@ -292,6 +293,19 @@ class Context:
         _check(self.L.se_amd_sample_cbd_device(self.h, _ptr(seeds), _ptr(ctr_base), seeds.shape[0],
                                                blocks_per_ct, _ptr(out), _stream_ptr()),
                "se_amd_sample_cbd_device")
+
+    def word_ops(self, prime, op, a, b=None, c=None):
+        """Device word arithmetic KAT hook: uint64 numpy operands in, uint32 numpy out."""
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        t = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint64).view(np.int64)).to(dev)
+        ta, tb, tc = t(a), t(b), t(c)
+        out = torch.zeros(ta.numel(), dtype=torch.int32, device=dev)
+        _check(self.L.se_amd_word_ops_device(self.h, prime, op, _ptr(ta), _ptr(tb), _ptr(tc), _ptr(out),
+                                             ta.numel(), _stream_ptr()), "se_amd_word_ops_device")
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint32)
 
     def pack_ternary(self, codes_np):
         import numpy as np

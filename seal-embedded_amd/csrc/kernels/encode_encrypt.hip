@@ -81,23 +81,31 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     const int t      = threadIdx.x;
 
     // ckks_common.c:139-153 scatters values[i] to both conjugate slots; the map is a bijection
-    // onto [0,n), so slot k is filled from values[inv_map[k] mod n/2].
+    // onto [0,n), so slot k is filled from values[inv_map[k] mod n/2].  The staging array is laid out
+    // through sv_slot() (se_types.h) so that the gather is bank-conflict-free; gather_map holds the
+    // LDS position directly.
     {
         const float4 *src = reinterpret_cast<const float4 *>(values + b * (N / 2));
-        float4 *dst       = reinterpret_cast<float4 *>(sv);
 #pragma unroll
-        for (int i = t; i < N / 8; i += TH) dst[i] = src[i];
+        for (int i = t; i < N / 8; i += TH)
+        {
+            const float4 v = src[i];
+            sv[sv_slot(4u * i, LOGN)]      = v.x;
+            sv[sv_slot(4u * i + 1u, LOGN)] = v.y;
+            sv[sv_slot(4u * i + 2u, LOGN)] = v.z;
+            sv[sv_slot(4u * i + 3u, LOGN)] = v.w;
+        }
     }
     __syncthreads();
     double re[16], im[16];
     {
-        const uint4 *mp = reinterpret_cast<const uint4 *>(T.inv_map + 16 * t);
+        const uint4 *mp = reinterpret_cast<const uint4 *>(T.gather_map + 16 * t);
         uint4 m0 = mp[0], m1 = mp[1];
         uint32_t packed[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
         for (int e = 0; e < 16; e++)
         {
-            uint32_t idx = (packed[e >> 1] >> (16 * (e & 1))) & (N / 2 - 1);
+            uint32_t idx = (packed[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
             re[e]        = (double)sv[idx];
             im[e]        = 0.0;
         }
@@ -128,8 +136,11 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     }
     else
     {
+        // |coefficient| == 2^63 passes the reference's check (it rejects only > 2^63,
+        // ckks_common.c:195) and its x86-64 conversion yields INT64_MIN for +2^63 as well
 #pragma unroll
-        for (int e = 0; e < 16; e++) m[e] = (int64_t)re[e];
+        for (int e = 0; e < 16; e++)
+            m[e] = (re[e] == 9223372036854775808.0) ? INT64_MIN : (int64_t)re[e];
     }
     const int all_ok = __syncthreads_and(ok);
     if (status && t == 0) status[b] = (uint8_t)all_ok;

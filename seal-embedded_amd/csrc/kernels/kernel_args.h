@@ -58,6 +58,8 @@ struct TernaryArgs
     uint64_t *ctr_out;
     uint32_t n;
     uint32_t B;
+    const uint64_t *ctr_in;  // optional [B]: start counters (NULL = 0, the encrypt path)
+    uint32_t num_cus;        // compute units of the device (0 = 256)
 };
 
 hipError_t launch_encode_encrypt(const DevParams &, const DevTables &, const EncArgs &, int mode,
@@ -91,6 +93,47 @@ hipError_t launch_spec_setup(const SpecPlan &, const uint8_t *seeds, uint8_t *se
                              hipStream_t);
 hipError_t launch_spec_select(const SpecPlan &, uint32_t n, uint64_t *ctr0, const uint64_t *ctrout_v,
                               const uint32_t *rows, uint32_t *c1, uint32_t *fail, hipStream_t);
+
+// ---- explicit-operand stage kernels behind the reference-named lower surface (stage_ops.hip) ----
+struct FftArgs
+{
+    const double *in;    // [count][n][2] interleaved complex128
+    double *out_cplx;    // [count][n][2] (optional in mode 1)
+    int64_t *out_int;    // mode 1: [count][n]
+    uint32_t *fail_idx;  // mode 1: [count], preset to 0xFFFFFFFF
+    int mode;            // 0 ifft_inpl, 1 ifft + round (ckks_encode_base tail), 2 fft_inpl
+};
+struct LowerSymArgs
+{
+    const uint8_t *s_small;  // [n/4] 2-bit packed secret key (shared by the batch)
+    const int64_t *pte;      // [count][n] m + e, or NULL ...
+    const int8_t *ep;        // ... then [count][n] small error (gen_pk)
+    const uint32_t *a;       // [count][n] uniform polynomial of this prime (NTT domain)
+    uint32_t *c0, *ntt_pte;  // [count][n]
+    uint32_t *s_save;        // optional [count][n]
+    int j;
+};
+struct LowerAsymArgs
+{
+    const uint8_t *u_small;  // [count][n/4] 2-bit packed u
+    const int8_t *e1;        // [count][n]
+    const int64_t *pte;      // [count][n] m + e0
+    const uint32_t *pk0, *pk1;  // [count][n] public key of this prime (in)
+    uint32_t *c0, *c1, *ntt_pte;  // [count][n] (out)
+    uint32_t *ntt_u_save, *ntt_e1_save;  // optional
+    int j;
+};
+hipError_t launch_fft_polys(const DevParams &, const DevTables &, const FftArgs &, size_t count, hipStream_t);
+hipError_t launch_reduce_poly(const DevParams &, int j, const int64_t *pte, const int8_t *e, uint32_t *out,
+                              bool add, size_t total, hipStream_t);
+hipError_t launch_word_ops(const DevParams &, int j, int op, const uint64_t *a, const uint64_t *b,
+                           const uint64_t *c, uint32_t *out, size_t count, hipStream_t);
+hipError_t launch_add_small(int64_t *m, const int8_t *e, size_t total, hipStream_t);
+hipError_t launch_expand_ternary(const uint8_t *packed, uint32_t *out, uint32_t q, uint32_t n, hipStream_t);
+hipError_t launch_lower_sym_prime(const DevParams &, const DevTables &, const LowerSymArgs &, size_t count,
+                                  hipStream_t);
+hipError_t launch_lower_asym_prime(const DevParams &, const DevTables &, const LowerAsymArgs &, size_t count,
+                                   hipStream_t);
 
 hipError_t launch_sample_cbd(const CbdArgs &, hipStream_t);
 hipError_t launch_sample_ternary(const TernaryArgs &, hipStream_t);

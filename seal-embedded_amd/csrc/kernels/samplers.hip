@@ -504,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_sample_ternary(TernaryArgs A)
     load_seed(seed, A.seeds, bs);
     int8_t *out = A.codes + bs * n;
 
-    uint64_t ctr  = 0;
+    uint64_t ctr  = A.ctr_in ? A.ctr_in[bs] : 0;
     uint32_t blk  = 0;                 // next block to draw
     uint32_t pend[3] = {0, 0, 0};      // pending rejected bytes of the current block
     uint32_t cur_base = 0;             // first coefficient of the current block
@@ -603,12 +603,13 @@ __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const 
 // launch workgroups of w waves (w = 1, 2, 3, 4, 8, 12, 16) and reserve > 80 KiB of dynamic LDS per
 // workgroup, which admits exactly one workgroup per CU: every CU gets the same number of waves
 // and the hardware deals a workgroup's waves round-robin over its 4 SIMDs.
-static void chain_geometry(size_t B, unsigned &threads, unsigned &grid, size_t &lds_bytes,
+static void chain_geometry(size_t B, unsigned num_cus, unsigned &threads, unsigned &grid, size_t &lds_bytes,
                            unsigned *master_waves = nullptr, bool allow_helpers = false,
                            size_t fill_to = 8)
 {
+    const size_t cus   = num_cus ? num_cus : 256;
     const size_t waves = (B + 63) / 64;
-    size_t w           = (waves + 255) / 256;   // waves per CU if spread over 256 CUs
+    size_t w           = (waves + cus - 1) / cus;   // waves per CU if spread over all CUs
     if (w < 1) w = 1;
     if (w > 4) w = ((w + 3) / 4) * 4;           // beyond one per SIMD: whole multiples of 4
     if (w > 16) w = 16;
@@ -625,7 +626,8 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
     if (A0.B == 0) return hipSuccess;
     unsigned threads, grid_x, mw;
     size_t lds;
-    chain_geometry(A0.B, threads, grid_x, lds, &mw, !(A0.debug_flags & 8), A0.helper_fill ? A0.helper_fill : 8);
+    chain_geometry(A0.B, P.num_cus, threads, grid_x, lds, &mw, !(A0.debug_flags & 8),
+                   A0.helper_fill ? A0.helper_fill : 8);
     UniformArgs A   = A0;
     A.master_waves  = mw;
     if (A.debug_flags & 16) A.spec = nullptr;  // A/B: helper waves without speculation
@@ -660,7 +662,7 @@ hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
     if (A.B == 0) return hipSuccess;
     unsigned threads, grid_x;
     size_t lds;
-    chain_geometry(A.B, threads, grid_x, lds);
+    chain_geometry(A.B, A.num_cus, threads, grid_x, lds);
     (void)hipFuncSetAttribute((const void *)k_sample_ternary, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(k_sample_ternary, dim3(grid_x), dim3(threads), lds, st, A);
@@ -702,7 +704,11 @@ __global__ __launch_bounds__(256) void k_spec_select(SpecPlan S, uint32_t n, uin
                                                      uint32_t *c1, uint32_t *fail)
 {
     const uint32_t b = blockIdx.x;
-    uint64_t ctr     = ctr0[b];
+    // every thread must have the start counter before thread 0 may overwrite ctr0[b] on a miss
+    __shared__ uint64_t start_ctr;
+    if (threadIdx.x == 0) start_ctr = ctr0[b];
+    __syncthreads();
+    uint64_t ctr = start_ctr;
     for (uint32_t j = 1; j < S.nprimes; j++)
     {
         const uint64_t g = ctr - S.base[j];   // wraps to a huge value when ctr < base

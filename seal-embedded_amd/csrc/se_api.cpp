@@ -9,6 +9,7 @@
 #include <string.h>
 #include <sys/random.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,11 +27,6 @@ using seamd::HostPipe;
 static_assert(seamd::kErrInvalid == SE_ERR_INVALD_ARGUMENT && seamd::kErrNoDevice == SE_ERR_NO_DEVICE &&
                   seamd::kErrHip == SE_ERR_HIP && seamd::kErrNoKey == SE_ERR_NO_KEY,
               "internal error codes must match the public header");
-
-struct se_amd_ctx
-{
-    Context c;
-};
 
 static hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -166,6 +162,7 @@ int se_amd_encrypt_sym_seeded_device(se_amd_ctx *ctx, const float *d_values, siz
     Context &c = ctx->c;
     if (B > c.a_cap)
     {
+        std::lock_guard<std::mutex> lk(c.mu);
         SEAMD_HIP(hipSetDevice(c.device));
         SEAMD_HIP(hipDeviceSynchronize());
         if (c.d_a) (void)hipFree(c.d_a);
@@ -262,15 +259,7 @@ int se_amd_sample_uniform_device(se_amd_ctx *ctx, const uint8_t *d_seeds, const 
                                  size_t B, uint32_t *d_out, uint64_t *d_ctr_out, void *stream)
 {
     if (!ctx || !d_seeds || !d_out) return SE_ERR_INVALD_ARGUMENT;
-    if (B == 0) return SE_SUCCESS;
-    SEAMD_HIP(hipSetDevice(ctx->c.device));
-    int rc = ctx->c.ensure_scratch(B);
-    if (rc) return rc;
-    const uint32_t np = (uint32_t)ctx->c.hp.nprimes;
-    seamd::UniformArgs ua{d_seeds, d_ctr_in, d_ctr_out, d_out, ctx->c.d_rej, ctx->c.rej_cap,
-                          (uint32_t)B, 0, np, np, ctx->c.d_spec, ctx->c.spec_cap, 0, ctx->c.debug_flags};
-    SEAMD_HIP(seamd::launch_sample_uniform(ctx->c.dp, ua, as_stream(stream)));
-    return SE_SUCCESS;
+    return ctx->c.sample_uniform(d_seeds, d_ctr_in, B, d_out, d_ctr_out, as_stream(stream));
 }
 
 int se_amd_sample_ternary_device(se_amd_ctx *ctx, const uint8_t *d_seeds, size_t B, int8_t *d_codes,
@@ -278,7 +267,8 @@ int se_amd_sample_ternary_device(se_amd_ctx *ctx, const uint8_t *d_seeds, size_t
 {
     if (!ctx || !d_seeds || !d_codes) return SE_ERR_INVALD_ARGUMENT;
     SEAMD_HIP(hipSetDevice(ctx->c.device));
-    seamd::TernaryArgs ta{d_seeds, d_codes, d_ctr_out, (uint32_t)ctx->c.hp.n, (uint32_t)B};
+    seamd::TernaryArgs ta{d_seeds, d_codes, d_ctr_out, (uint32_t)ctx->c.hp.n, (uint32_t)B, nullptr,
+                          (uint32_t)ctx->c.num_cus};
     SEAMD_HIP(seamd::launch_sample_ternary(ta, as_stream(stream)));
     return SE_SUCCESS;
 }
@@ -299,6 +289,15 @@ void se_amd_pack_ternary_host(const int8_t *codes, size_t n, uint8_t *packed)
     memset(packed, 0, n / 4);
     for (size_t i = 0; i < n; i++)
         packed[i / 4] |= (uint8_t)((codes[i] & 3) << (6 - 2 * (i % 4)));
+}
+
+int se_amd_word_ops_device(se_amd_ctx *ctx, size_t prime, int op, const uint64_t *d_a, const uint64_t *d_b,
+                           const uint64_t *d_c, uint32_t *d_out, size_t count, void *stream)
+{
+    if (!ctx || !d_a || !d_out || prime >= ctx->c.hp.nprimes || op < 0 || op > 12) return SE_ERR_INVALD_ARGUMENT;
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    SEAMD_HIP(seamd::launch_word_ops(ctx->c.dp, (int)prime, op, d_a, d_b, d_c, d_out, count, as_stream(stream)));
+    return SE_SUCCESS;
 }
 
 int se_amd_set_profiling(se_amd_ctx *ctx, int enabled)
@@ -330,7 +329,7 @@ int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;
     ctx->c.rej_cap     = cap;
-    ctx->c.scratch_cap = 0;  // force re-allocation with the new stride
+    ctx->c.rows_cap    = 0;  // force re-allocation with the new stride
     return SE_SUCCESS;
 }
 
@@ -399,13 +398,14 @@ int se_amd_set_speculation_capacity(se_amd_ctx *ctx, uint32_t cap)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;
     ctx->c.spec_cap    = cap ? cap : 1;
-    ctx->c.scratch_cap = 0;  // force re-allocation with the new stride
+    ctx->c.rows_cap    = 0;  // force re-allocation with the new stride
     return SE_SUCCESS;
 }
 
 int se_amd_reserve(se_amd_ctx *ctx, size_t B)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
     return ctx->c.ensure_scratch(B);
 }
 
@@ -477,8 +477,7 @@ int se_amd_encrypt_asym_host(se_amd_ctx *ctx, const float *values, size_t B, con
 static Parms g_parms;
 static SE_PTRS g_ptrs;
 static SE_PARMS g_se_parms;
-static std::vector<Modulus> g_moduli;
-static std::vector<uint8_t> g_pool;
+static std::vector<uint32_t> g_roots;  // [np][n] one-shot NTT roots (SE_PTRS::ntt_roots_ptr per prime)
 static se_amd_ctx *g_ctx = nullptr;
 // further contexts, one per additional device of $SE_AMD_DEVICES: se_encrypt_batch shards a batch
 // over all of them (contiguous blocks, one host thread and one PCIe link per device)
@@ -490,14 +489,8 @@ static const char *data_path()
     return p ? p : "adapter_output_data";  // device/CMakeLists.txt:115,285
 }
 
-SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals, const ZZ *ratios,
-                          double scale, EncryptType encrypt_type)
+static void drop_contexts()
 {
-    // Custom moduli are unreachable in the reference (ckks_setup_custom recurses, ckks_common.c:90);
-    // like se_setup, fall back to the default parameter set for (degree, nprimes).
-    (void)modulus_vals;
-    (void)ratios;
-    (void)scale;  // overwritten by the parameter set (parameters.c:190-226)
     if (g_ctx)
     {
         se_amd_destroy(g_ctx);
@@ -505,8 +498,13 @@ SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals,
     }
     for (se_amd_ctx *x : g_more) se_amd_destroy(x);
     g_more.clear();
-    // devices: $SE_AMD_DEVICES = "all" or a comma list (batched entry shards over them); otherwise
-    // the single device $SE_AMD_DEVICE (default 0)
+}
+
+// $SE_AMD_DEVICES = "all" or a comma list (the batched entry shards over them); otherwise the single
+// device $SE_AMD_DEVICE (default 0).  Indices are HIP device ordinals, i.e. positions in the
+// process's visible-device list: $HIP_VISIBLE_DEVICES / $ROCR_VISIBLE_DEVICES remap them as usual.
+static std::vector<int> device_list()
+{
     std::vector<int> devices;
     if (const char *list = getenv("SE_AMD_DEVICES"))
     {
@@ -529,12 +527,53 @@ SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals,
         }
     }
     if (devices.empty()) devices.push_back(getenv("SE_AMD_DEVICE") ? atoi(getenv("SE_AMD_DEVICE")) : 0);
-    const bool asym = (encrypt_type == SE_ASYM_ENCR);
+    return devices;
+}
+
+SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals, const ZZ *ratios,
+                          double scale, EncryptType encrypt_type)
+{
+    // Same sequence as seal_embedded.c:24-83: flags, pool, pointer carving, ckks_setup, ckks_setup_s
+    // -- all through the lower surface of this library (se_lower.cpp).
+    if (modulus_vals && ratios)
+    {
+        // unreachable in the reference (ckks_setup_custom recurses forever, ckks_common.c:90);
+        // encrypting under a different chain than the caller asked for would be silent corruption
+        fprintf(stderr, "Error! se_setup_custom: custom modulus chains are not supported\n");
+        exit(1);
+    }
+    drop_contexts();
+    if (g_ptrs.conj_vals) free(g_ptrs.conj_vals);
+    g_ptrs = SE_PTRS();
+    delete_parameters(&g_parms);
+
+    const bool asym       = (encrypt_type == SE_ASYM_ENCR);
+    const size_t n        = degree;
+    g_parms.scale         = scale;  // overwritten by the parameter set (parameters.c:190-226)
+    g_parms.is_asymmetric = asym;
+    g_parms.pk_from_file  = 1;
+    g_parms.sample_s      = 0;
+    g_parms.small_u       = 1;
+    g_parms.small_s       = 1;
+    g_se_parms.parms      = &g_parms;
+    g_se_parms.se_ptrs    = &g_ptrs;
+
+    ZZ *mempool = asym ? ckks_mempool_setup_asym(n) : ckks_mempool_setup_sym(n);
+    if (asym)
+        ckks_set_ptrs_asym(n, mempool, &g_ptrs);
+    else
+        ckks_set_ptrs_sym(n, mempool, &g_ptrs);
+    ckks_setup(n, nprimes, g_ptrs.index_map_ptr, &g_parms);
+    if (!asym) ckks_setup_s(&g_parms, NULL, NULL, g_ptrs.ternary);  // sk_<n>.dat -> SE_PTRS::ternary
+
+    const std::vector<int> devices = device_list();
     for (size_t i = 0; i < devices.size(); i++)
     {
         se_amd_ctx *x = nullptr;
         int rc        = se_amd_create(&x, degree, nprimes, devices[i]);
-        if (rc == SE_SUCCESS) rc = se_amd_load_keys_from_dir(x, data_path(), asym ? 1 : 0);
+        if (rc == SE_SUCCESS)
+            rc = asym ? se_amd_load_keys_from_dir(x, data_path(), 1)
+                      : se_amd_set_secret_key(x, reinterpret_cast<const uint8_t *>(g_ptrs.ternary));
         if (rc != SE_SUCCESS)
         {
             // error convention of the reference: print and exit (ckks_sym.c:68-72, fileops.c:60-91)
@@ -546,53 +585,13 @@ SE_PARMS *se_setup_custom(size_t degree, size_t nprimes, const ZZ *modulus_vals,
         else
             g_more.push_back(x);
     }
-    const Context &c = g_ctx->c;
-    const size_t n   = c.hp.n;
-    g_moduli.assign(nprimes, Modulus());
+    g_roots.assign(nprimes * n, 0);
     for (size_t j = 0; j < nprimes; j++)
     {
-        g_moduli[j].value          = c.hp.q[j];
-        g_moduli[j].const_ratio[0] = c.hp.cr_lo[j];
-        g_moduli[j].const_ratio[1] = c.hp.cr_hi[j];
+        std::vector<uint32_t> rw;
+        seamd::host_ntt_root_pairs(g_ctx->c.hp, j, rw);
+        for (size_t i = 0; i < n; i++) g_roots[j * n + i] = rw[2 * i];
     }
-    g_parms.coeff_count      = n;
-    g_parms.logn             = c.hp.logn;
-    g_parms.moduli           = g_moduli.data();
-    g_parms.curr_modulus     = g_moduli.data();
-    g_parms.curr_modulus_idx = 0;
-    g_parms.nprimes          = nprimes;
-    g_parms.scale            = c.hp.scale;
-    g_parms.is_asymmetric    = asym;
-    g_parms.pk_from_file     = 1;
-    g_parms.sample_s         = 0;
-    g_parms.small_u          = 1;
-    g_parms.small_s          = 1;
-
-    // host staging pool: conj_vals (16n) | values (2n) | c0 (4n) | c1 (4n) | index_map (2n)
-    // | ternary (n/4) | e1 (n).  The reference's aliasing plan (ckks_sym.c:29-160) is not
-    // reproduced; SE_PTRS fields stay valid for callers that inspect them.
-    g_pool.assign(16 * n + 2 * n + 4 * n + 4 * n + 2 * n + n / 4 + n + 64, 0);
-    uint8_t *p             = g_pool.data();
-    g_ptrs.conj_vals       = reinterpret_cast<double *>(p);
-    g_ptrs.conj_vals_int_ptr = reinterpret_cast<int64_t *>(p);
-    p += 16 * n;
-    g_ptrs.values = reinterpret_cast<flpt *>(p);
-    p += 2 * n;
-    g_ptrs.c0_ptr = reinterpret_cast<ZZ *>(p);
-    p += 4 * n;
-    g_ptrs.c1_ptr      = reinterpret_cast<ZZ *>(p);
-    g_ptrs.ntt_pte_ptr = g_ptrs.c1_ptr;  // same address as in the reference (ckks_sym.c:86-88)
-    p += 4 * n;
-    g_ptrs.index_map_ptr = reinterpret_cast<uint16_t *>(p);
-    memcpy(p, c.index_map.data(), 2 * n);
-    p += 2 * n;
-    g_ptrs.ternary = reinterpret_cast<ZZ *>(p);
-    p += n / 4;
-    g_ptrs.e1_ptr        = reinterpret_cast<int8_t *>(p);
-    g_ptrs.ifft_roots    = nullptr;
-    g_ptrs.ntt_roots_ptr = nullptr;
-    g_se_parms.parms     = &g_parms;
-    g_se_parms.se_ptrs   = &g_ptrs;
     return &g_se_parms;
 }
 
@@ -640,40 +639,56 @@ bool se_encrypt_seeded(uint8_t *shareable_seed, uint8_t *seed, SEND_FNCT_PTR net
     fill_seed(s_share, shareable_seed);
     fill_seed(s_priv, seed);
 
+    // one GPU call for the whole ciphertext (all primes), then the reference's per-prime delivery
     std::vector<uint32_t> c0(np * n), c1(np * n), ntt_pte(np * n);
+    std::vector<int64_t> pte(n);
     int rc;
     if (parms->is_asymmetric)
         rc = se_amd_encrypt_asym_host(g_ctx, ptrs->values, 1, s_priv, c0.data(), c1.data(),
-                                      ntt_pte.data(), ptrs->conj_vals_int_ptr, nullptr);
+                                      ntt_pte.data(), pte.data(), nullptr);
     else
         rc = se_amd_encrypt_sym_host(g_ctx, ptrs->values, 1, s_share, s_priv, c0.data(), c1.data(),
-                                     ntt_pte.data(), ptrs->conj_vals_int_ptr, nullptr);
+                                     ntt_pte.data(), pte.data(), nullptr);
     if (rc < 0)
     {
         fprintf(stderr, "Error! se_encrypt: %s\n", se_amd_last_error());
         exit(1);
     }
     if (rc > 0) return false;  // encode overflow (seal_embedded.c:115-118)
+    // SE_PTRS as the reference leaves it: m + e in the low half of conj_vals; u and e1 of this call
+    memcpy(ptrs->conj_vals_int_ptr, pte.data(), n * sizeof(int64_t));
+    if (parms->is_asymmetric)
+    {
+        std::vector<int8_t> codes(n);
+        if (g_ctx->c.fetch_asym_randomness(codes.data(), ptrs->e1_ptr) != 0)
+        {
+            fprintf(stderr, "Error! se_encrypt: %s\n", se_amd_last_error());
+            exit(1);
+        }
+        se_amd_pack_ternary_host(codes.data(), n, reinterpret_cast<uint8_t *>(ptrs->ternary));
+    }
 
     const char *quirk  = getenv("SE_AMD_REFERENCE_C1_ALIAS");
     const bool alias   = !parms->is_asymmetric && quirk && quirk[0] == '1';
-    parms->curr_modulus_idx = 0;
+    reset_primes(parms);
     for (size_t j = 0; j < np; j++)
     {
-        parms->curr_modulus_idx = j;
-        parms->curr_modulus     = &parms->moduli[j];
+        memcpy(ptrs->ntt_roots_ptr, g_roots.data() + j * n, n * sizeof(ZZ));
         memcpy(ptrs->c0_ptr, c0.data() + j * n, n * sizeof(ZZ));
+        if (parms->is_asymmetric) memcpy(ptrs->ntt_pte_ptr, ntt_pte.data() + j * n, n * sizeof(ZZ));
         memcpy(ptrs->c1_ptr, (alias ? ntt_pte.data() : c1.data()) + j * n, n * sizeof(ZZ));
         if (print)
         {
-            // text format of util_print.h:499-508: "name : { v0, v1, ... }"
+            // print_poly("c0: ", ...) of seal_embedded.c:160-163 with the default SE_PRINT_SMALL
+            // (defines.h:49-50, util_print.h:478-488): the first 8 values, then "... }"
             const ZZ *polys[2]   = {ptrs->c0_ptr, ptrs->c1_ptr};
             const char *names[2] = {"c0: ", "c1: "};
             for (int k = 0; k < 2; k++)
             {
+                const size_t shown = n < 8 ? n : 8;
                 printf("%s : { ", names[k]);
-                for (size_t i = 0; i < n; i++) printf(i + 1 < n ? "%u, " : "%u", polys[k][i]);
-                printf(" }\n");
+                for (size_t i = 0; i < shown; i++) printf(i + 1 < n ? "%u, " : "%u ", polys[k][i]);
+                printf(shown == n ? "}\n" : "... }\n");
             }
         }
         if (network_send_function)
@@ -682,6 +697,7 @@ bool se_encrypt_seeded(uint8_t *shareable_seed, uint8_t *seed, SEND_FNCT_PTR net
             if (network_send_function(ptrs->c0_ptr, nbytes) != nbytes) return false;
             if (network_send_function(ptrs->c1_ptr, nbytes) != nbytes) return false;
         }
+        if (j + 1 < np) next_modulus(parms);  // ckks_next_prime_* (seal_embedded.c:206-212)
     }
     return true;
 }
@@ -694,15 +710,15 @@ bool se_encrypt(SEND_FNCT_PTR network_send_function, void *v, size_t vlen_bytes,
 
 void se_cleanup(SE_PARMS *se_parms)
 {
-    if (g_ctx)
+    drop_contexts();
+    g_roots.clear();
+    if (se_parms && se_parms->parms) delete_parameters(se_parms->parms);  // seal_embedded.c:227
+    // the pool is freed through conj_vals, which points at its start (seal_embedded.c:230-232)
+    if (se_parms && se_parms->se_ptrs && se_parms->se_ptrs->conj_vals)
     {
-        se_amd_destroy(g_ctx);
-        g_ctx = nullptr;
+        free(se_parms->se_ptrs->conj_vals);
+        *se_parms->se_ptrs = SE_PTRS();
     }
-    for (se_amd_ctx *x : g_more) se_amd_destroy(x);
-    g_more.clear();
-    g_pool.clear();
-    g_moduli.clear();
     if (se_parms) se_parms->parms = 0;  // seal_embedded.c:234
 }
 

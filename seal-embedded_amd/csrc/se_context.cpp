@@ -23,6 +23,30 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 const std::string &last_error() { return g_last_error; }
 
+namespace {
+// temporary device allocation, wiped and freed on every path out of its scope
+struct DevTemp
+{
+    void *p      = nullptr;
+    size_t bytes = 0;
+    bool wipe    = false;
+    hipError_t alloc(size_t n, bool secret = false)
+    {
+        bytes = n;
+        wipe  = secret;
+        return hipMalloc(&p, n);
+    }
+    ~DevTemp()
+    {
+        if (!p) return;
+        if (wipe) (void)hipMemset(p, 0, bytes);
+        (void)hipFree(p);
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+}  // namespace
+
 int hip_fail(hipError_t e, const char *what)
 {
     char buf[512];
@@ -45,11 +69,12 @@ Context::~Context()
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_cbd) (void)hipEventDestroy(ev_cbd);
     if (ev_enc) (void)hipEventDestroy(ev_enc);
+    if (ev_done) (void)hipEventDestroy(ev_done);
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
     for (auto &sp : sp_streams)
         if (sp && sp != aux_stream) (void)hipStreamDestroy(sp);
-    void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map,
+    void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
                     d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec,
                     d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail};
     for (void *p : ptrs)
@@ -77,7 +102,11 @@ int Context::init(size_t n, size_t nprimes, int dev)
     }
     device = dev;
     SEAMD_HIP(hipSetDevice(device));
-    dp = to_dev_params(hp);
+    if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+        num_cus <= 0)
+        num_cus = 256;
+    dp         = to_dev_params(hp);
+    dp.num_cus = (uint32_t)num_cus;
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
     // rej_cap >= 3x the expected rejections per polynomial; spec_cap ~ mean + >5 sigma of the draws
     // speculation capacity: the helper waves compute this many candidates per polynomial WHILE the
@@ -115,6 +144,7 @@ int Context::init(size_t n, size_t nprimes, int dev)
     SEAMD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_cbd, hipEventDisableTiming));
     SEAMD_HIP(hipEventCreateWithFlags(&ev_enc, hipEventDisableTiming));
+    SEAMD_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
     for (size_t j = 0; j < (size_t)kMaxPrimes; j++)
         SEAMD_HIP(hipEventCreateWithFlags(&ev_prime[j], hipEventDisableTiming));
     {
@@ -132,29 +162,88 @@ int Context::init(size_t n, size_t nprimes, int dev)
         dt.intt_rw   = d_intt_rw;
         dt.index_map = d_map;
     }
+    {
+        std::vector<uint16_t> gather(n);
+        for (size_t k = 0; k < n; k++)
+            gather[k] = (uint16_t)sv_slot((uint32_t)(inv[k] & (n / 2 - 1)), (uint32_t)hp.logn);
+        SEAMD_HIP(hipMalloc((void **)&d_gather, n * sizeof(uint16_t)));
+        SEAMD_HIP(hipMemcpy(d_gather, gather.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+        dt.gather_map = d_gather;
+    }
     dt.inv_map = d_inv_map;
     dt.ifft_w  = d_ifft_w;
     dt.ntt_rw  = d_ntt_rw;
     return 0;
 }
 
-int Context::ensure_scratch(size_t B)
+int Context::ensure_scratch(size_t B, size_t rows)
 {
-    if (B <= scratch_cap) return 0;
+    // d_err / d_ucodes / d_ctr are per real ciphertext; the reject lists and speculation rows are
+    // also needed by the virtual ciphertexts of the small-batch path, which need nothing else
+    if (rows < B) rows = B;
+    if (B <= scratch_cap && rows <= rows_cap) return 0;
     SEAMD_HIP(hipSetDevice(device));
     SEAMD_HIP(hipDeviceSynchronize());
-    void *old[] = {d_err, d_ucodes, d_ctr, d_rej, d_spec};
-    for (void *p : old)
-        if (p) (void)hipFree(p);
-    d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_rej = nullptr, d_spec = nullptr;
-    scratch_cap    = 0;
     const size_t n = hp.n;
-    SEAMD_HIP(hipMalloc((void **)&d_err, B * 2 * n));
-    SEAMD_HIP(hipMalloc((void **)&d_ucodes, B * n));
-    SEAMD_HIP(hipMalloc((void **)&d_ctr, B * sizeof(uint64_t)));
-    SEAMD_HIP(hipMalloc((void **)&d_rej, B * (size_t)(rej_cap ? rej_cap : 1) * sizeof(uint32_t)));
-    SEAMD_HIP(hipMalloc((void **)&d_spec, B * (size_t)spec_cap * sizeof(uint32_t)));
-    scratch_cap = B;
+    if (B > scratch_cap)
+    {
+        void *old[] = {d_err, d_ucodes, d_ctr};
+        for (void *p : old)
+            if (p) (void)hipFree(p);
+        d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr;
+        scratch_cap = 0;
+        SEAMD_HIP(hipMalloc((void **)&d_err, B * 2 * n));
+        SEAMD_HIP(hipMalloc((void **)&d_ucodes, B * n));
+        SEAMD_HIP(hipMalloc((void **)&d_ctr, B * sizeof(uint64_t)));
+        scratch_cap = B;
+    }
+    if (rows > rows_cap)
+    {
+        if (d_rej) (void)hipFree(d_rej);
+        if (d_spec) (void)hipFree(d_spec);
+        d_rej = nullptr, d_spec = nullptr;
+        rows_cap = 0;
+        SEAMD_HIP(hipMalloc((void **)&d_rej, rows * (size_t)(rej_cap ? rej_cap : 1) * sizeof(uint32_t)));
+        SEAMD_HIP(hipMalloc((void **)&d_spec, rows * (size_t)spec_cap * sizeof(uint32_t)));
+        rows_cap = rows;
+    }
+    return 0;
+}
+
+// Successive calls share the context's scratch and auxiliary streams: order them.  The caller
+// holds `mu`.
+int Context::begin_call(hipStream_t st)
+{
+    SEAMD_HIP(hipSetDevice(device));
+    if (have_done) SEAMD_HIP(hipStreamWaitEvent(st, ev_done, 0));
+    return 0;
+}
+
+int Context::end_call(hipStream_t st, int rc)
+{
+    if (rc != 0)
+    {
+        // a launch failed part-way: auxiliary streams may be forked and un-joined; drain the device
+        // so nothing still refers to the scratch, keep the first error
+        const std::string first = last_error();
+        (void)hipDeviceSynchronize();
+        set_last_error(first);
+        return rc;
+    }
+    SEAMD_HIP(hipEventRecord(ev_done, st));
+    have_done = true;
+    return 0;
+}
+
+int Context::fetch_asym_randomness(int8_t *ucodes, int8_t *e1)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    if (!d_ucodes || !d_err) return kErrInvalid;
+    SEAMD_HIP(hipSetDevice(device));
+    SEAMD_HIP(hipDeviceSynchronize());
+    const size_t n = hp.n;
+    SEAMD_HIP(hipMemcpy(ucodes, d_ucodes, n, hipMemcpyDeviceToHost));
+    SEAMD_HIP(hipMemcpy(e1, d_err + n, n, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -163,9 +252,16 @@ int Context::ensure_scratch(size_t B)
 // per-ciphertext path.
 int Context::set_secret_key(const uint8_t *sk_packed)
 {
+    std::lock_guard<std::mutex> lk(mu);
     const size_t n = hp.n, np = hp.nprimes;
     SEAMD_HIP(hipSetDevice(device));
     std::vector<uint32_t> expanded(np * n);
+    // the expanded key never outlives this call, on either side of the bus
+    struct Wipe
+    {
+        std::vector<uint32_t> &v;
+        ~Wipe() { explicit_bzero(v.data(), v.size() * sizeof(uint32_t)); }
+    } wipe{expanded};
     for (size_t j = 0; j < np; j++)
         for (size_t i = 0; i < n; i++)
         {
@@ -177,14 +273,14 @@ int Context::set_secret_key(const uint8_t *sk_packed)
             }
             expanded[j * n + i] = code + (code == 0 ? hp.q[j] : 0u) - 1u;
         }
-    uint32_t *d_tmp = nullptr;
-    SEAMD_HIP(hipMalloc((void **)&d_tmp, np * n * sizeof(uint32_t)));
+    DevTemp tmp;
+    SEAMD_HIP(tmp.alloc(np * n * sizeof(uint32_t), true));
+    uint32_t *d_tmp = tmp.as<uint32_t>();
     if (!d_s_hat) SEAMD_HIP(hipMalloc((void **)&d_s_hat, 2 * np * n * sizeof(uint32_t)));
     SEAMD_HIP(hipMemcpy(d_tmp, expanded.data(), np * n * sizeof(uint32_t), hipMemcpyHostToDevice));
     for (size_t j = 0; j < np; j++)
         SEAMD_HIP(launch_ntt_polys(dp, dt, (int)j, d_tmp + j * n, d_s_hat + 2 * j * n, 1, nullptr));
     SEAMD_HIP(hipDeviceSynchronize());
-    SEAMD_HIP(hipFree(d_tmp));
     dt.s_hat = d_s_hat;
     have_sk  = true;
     return 0;
@@ -203,8 +299,10 @@ int Context::set_public_key(const uint32_t *pk0, const uint32_t *pk1)
                 set_last_error("public key coefficient not reduced modulo its prime");
                 return kErrInvalid;
             }
-    uint32_t *d_tmp = nullptr;
-    SEAMD_HIP(hipMalloc((void **)&d_tmp, 2 * np * n * sizeof(uint32_t)));
+    std::lock_guard<std::mutex> lk(mu);
+    DevTemp tmp;
+    SEAMD_HIP(tmp.alloc(2 * np * n * sizeof(uint32_t)));
+    uint32_t *d_tmp = tmp.as<uint32_t>();
     if (!d_pk0) SEAMD_HIP(hipMalloc((void **)&d_pk0, 2 * np * n * sizeof(uint32_t)));
     if (!d_pk1) SEAMD_HIP(hipMalloc((void **)&d_pk1, 2 * np * n * sizeof(uint32_t)));
     SEAMD_HIP(hipMemcpy(d_tmp, pk0, np * n * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -215,7 +313,6 @@ int Context::set_public_key(const uint32_t *pk0, const uint32_t *pk1)
         SEAMD_HIP(launch_make_pairs(d_tmp + np * n + j * n, d_pk1 + 2 * j * n, hp.q[j], n, nullptr));
     }
     SEAMD_HIP(hipDeviceSynchronize());
-    SEAMD_HIP(hipFree(d_tmp));
     dt.pk0  = d_pk0;
     dt.pk1  = d_pk1;
     have_pk = true;
@@ -231,13 +328,15 @@ int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, co
 {
     int rc = set_secret_key(sk_packed);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(mu);
     rc = ensure_scratch(1);
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
-    uint8_t *d_seeds = nullptr;
-    uint32_t *d_c    = nullptr;  // [2][np][n]: residues/pk0 then a/pk1
-    SEAMD_HIP(hipMalloc((void **)&d_seeds, 128));
-    SEAMD_HIP(hipMalloc((void **)&d_c, (size_t)2 * np * n * sizeof(uint32_t)));
+    DevTemp seeds, slab;  // slab [2][np][n]: residues/pk0 then a/pk1
+    SEAMD_HIP(seeds.alloc(128, true));
+    SEAMD_HIP(slab.alloc((size_t)2 * np * n * sizeof(uint32_t)));
+    uint8_t *d_seeds = seeds.as<uint8_t>();
+    uint32_t *d_c    = slab.as<uint32_t>();
     SEAMD_HIP(hipMemcpy(d_seeds, ep_seed, 64, hipMemcpyHostToDevice));
     SEAMD_HIP(hipMemcpy(d_seeds + 64, pk_seed, 64, hipMemcpyHostToDevice));
     uint32_t *d_p0 = d_c, *d_p1 = d_c + (size_t)np * n;
@@ -254,8 +353,7 @@ int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, co
     SEAMD_HIP(hipDeviceSynchronize());
     SEAMD_HIP(hipMemcpy(pk0_out, d_p0, (size_t)np * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     SEAMD_HIP(hipMemcpy(pk1_out, d_p1, (size_t)np * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    SEAMD_HIP(hipFree(d_seeds));
-    SEAMD_HIP(hipFree(d_c));
+    SEAMD_HIP(hipMemset(d_err, 0, n));  // the key-generation error is secret too
     return 0;
 }
 
@@ -297,6 +395,47 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
                          const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
                          uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, hipStream_t st)
 {
+    std::lock_guard<std::mutex> lk(mu);
+    int rc = begin_call(st);
+    if (rc) return rc;
+    rc = encrypt_sym_impl(d_values, B, d_share_seeds, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte, d_status, st);
+    return end_call(st, rc);
+}
+
+int Context::encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
+                          uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
+                          hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    int rc = begin_call(st);
+    if (rc) return rc;
+    rc = encrypt_asym_impl(d_values, B, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte, d_status, st);
+    return end_call(st, rc);
+}
+
+int Context::sample_uniform(const uint8_t *d_seeds, const uint64_t *d_ctr_in, size_t B, uint32_t *d_out,
+                            uint64_t *d_ctr_out, hipStream_t st)
+{
+    if (B == 0) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    int rc = begin_call(st);
+    if (rc) return rc;
+    rc = ensure_scratch(B);
+    if (rc == 0)
+    {
+        const uint32_t np = (uint32_t)hp.nprimes;
+        UniformArgs ua{d_seeds, d_ctr_in, d_ctr_out, d_out, d_rej, rej_cap, (uint32_t)B, 0, np, np,
+                       d_spec,  spec_cap, 0,         debug_flags};
+        hipError_t e = launch_sample_uniform(dp, ua, st);
+        if (e != hipSuccess) rc = hip_fail(e, "launch_sample_uniform");
+    }
+    return end_call(st, rc);
+}
+
+int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_share_seeds,
+                              const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
+                              uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, hipStream_t st)
+{
     if (!have_sk)
     {
         set_last_error("symmetric encryption needs a secret key (se_amd_set_secret_key)");
@@ -319,7 +458,7 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
     EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
 
-    const size_t chain_waves_per_cu = ((B + 63) / 64 + 255) / 256;
+    const size_t chain_waves_per_cu = ((B + 63) / 64 + (size_t)num_cus - 1) / (size_t)num_cus;
     const bool split = split_mode == 1 || (split_mode == 2 && (hp.n >= 8192 || chain_waves_per_cu < 4));
     if (!split)
     {
@@ -456,7 +595,7 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
     const size_t B     = plan.B;
     const uint32_t n   = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
     const size_t total = plan.total;
-    int rc             = ensure_scratch(B + total);  // reject lists / candidates of the virtual ciphertexts too
+    int rc             = ensure_scratch(B, B + total);  // reject lists / candidates of the virtual ciphertexts too
     if (rc) return rc;
     if (total > sp_cap)
     {
@@ -559,9 +698,9 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
     return 0;
 }
 
-int Context::encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
-                          uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
-                          hipStream_t st)
+int Context::encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
+                               uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
+                               hipStream_t st)
 {
     if (!have_pk)
     {
@@ -594,7 +733,7 @@ int Context::encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seed
     {
         const size_t lo = B * c / nchunks, hi = B * (c + 1) / nchunks, cb = hi - lo;
         if (cb == 0) continue;
-        TernaryArgs ta{d_seeds + lo * 64, d_ucodes + lo * n, d_ctr + lo, n, (uint32_t)cb};
+        TernaryArgs ta{d_seeds + lo * 64, d_ucodes + lo * n, d_ctr + lo, n, (uint32_t)cb, nullptr, (uint32_t)num_cus};
         stage_begin(2, ax);
         SEAMD_HIP(launch_sample_ternary(ta, ax));
         stage_end(ax);

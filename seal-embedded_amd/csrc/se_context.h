@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct Context
     uint32_t *d_ntt_rw  = nullptr;
     uint32_t *d_intt_rw = nullptr;
     uint16_t *d_map     = nullptr;
+    uint16_t *d_gather  = nullptr;
     uint32_t *d_s_hat   = nullptr;
     uint32_t *d_pk0     = nullptr;
     uint32_t *d_pk1     = nullptr;
@@ -65,7 +67,8 @@ struct Context
     size_t sp_cap = 0, sp_fail_cap = 0;
     uint32_t small_limit = getenv("SE_AMD_SMALL_LIMIT") ? (uint32_t)atoi(getenv("SE_AMD_SMALL_LIMIT")) : 65536;  // virtual ciphertexts a small call may fan out to
     hipStream_t sp_streams[kMaxPrimes] = {};
-    size_t scratch_cap = 0;
+    size_t scratch_cap = 0;   // ciphertexts d_err / d_ucodes / d_ctr hold
+    size_t rows_cap    = 0;   // rows of d_rej / d_spec (>= scratch_cap: virtual ciphertexts need only these)
     uint32_t rej_cap   = 256;
     uint32_t debug_flags = 0;  // timing ablations of the uniform sampler (tests/tools only)
 
@@ -74,6 +77,13 @@ struct Context
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cbd = nullptr, ev_enc = nullptr;
     hipEvent_t ev_prime[kMaxPrimes] = {};
+    // One set of scratch per context: successive calls are ordered on it.  Host threads serialise on
+    // `mu`; a call waits (on its own stream) for `ev_done` of the previous call, whatever stream
+    // that one ran on, before it touches the scratch or forks the auxiliary streams.
+    std::mutex mu;
+    hipEvent_t ev_done = nullptr;
+    bool have_done     = false;
+    int num_cus        = 256;
     bool overlap = true;   // run independent kernels on the auxiliary stream
     int split_mode = 2;    // symmetric path: 0 = fused kernel, 1 = per-prime software pipeline
                            // (encode_rns + uniform_j || ntt_fuse_{j-1}), 2 = choose per call: the split
@@ -92,12 +102,17 @@ struct Context
 
     ~Context();
     int init(size_t n, size_t nprimes, int device);
-    int ensure_scratch(size_t B);
+    int ensure_scratch(size_t B, size_t rows = 0);
+    int begin_call(hipStream_t st);
+    int end_call(hipStream_t st, int rc);
+    // u codes (0/1/2 per coefficient) and e1 of ciphertext 0 of the last asymmetric call (host out)
+    int fetch_asym_randomness(int8_t *ucodes, int8_t *e1);
     int set_secret_key(const uint8_t *sk_packed);
     int set_public_key(const uint32_t *pk0, const uint32_t *pk1);
     int gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, const uint8_t *ep_seed,
                        uint32_t *pk0_out, uint32_t *pk1_out);
 
+    // public entries: serialised on the context's scratch (begin_call / end_call around *_impl)
     int encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share_seeds,
                     const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,
                     int64_t *d_pte, uint8_t *d_status, hipStream_t st);
@@ -106,6 +121,14 @@ struct Context
                      hipStream_t st);
     int encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_t *d_pte,
                    uint8_t *d_status, hipStream_t st);
+    int sample_uniform(const uint8_t *d_seeds, const uint64_t *d_ctr_in, size_t B, uint32_t *d_out,
+                       uint64_t *d_ctr_out, hipStream_t st);
+    int encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_share_seeds,
+                         const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,
+                         int64_t *d_pte, uint8_t *d_status, hipStream_t st);
+    int encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
+                          uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
+                          hipStream_t st);
     // Small batches (a handful of ciphertexts): all primes' uniform samplers at once under guessed
     // start counters (kernels/samplers.hip, k_spec_*).  small_batch_plan says whether a batch
     // qualifies (encrypt_sym dispatches on it).  A counter outside its window (~1e-7 per prime) is
@@ -124,6 +147,12 @@ void set_last_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 
 }  // namespace seamd
+
+// the opaque handle of include/seal_embedded_amd.h
+struct se_amd_ctx
+{
+    seamd::Context c;
+};
 
 #define SEAMD_HIP(call)                                             \
     do                                                              \

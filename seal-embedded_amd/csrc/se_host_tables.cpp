@@ -51,6 +51,15 @@ uint32_t psi_of(const PrimeRow &r, size_t n)
 }
 }  // namespace
 
+bool host_known_prime(uint32_t q)
+{
+    for (const PrimeRow &r : k27)
+        if (r.q == q) return true;
+    for (const PrimeRow &r : k30)
+        if (r.q == q) return true;
+    return false;
+}
+
 int host_params_init(HostParams &hp, size_t n, size_t nprimes)
 {
     hp = HostParams();

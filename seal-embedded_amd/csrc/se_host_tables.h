@@ -22,6 +22,7 @@ struct HostParams
 // 0 on success; negative if (n, nprimes) is not one of the reference's default parameter sets.
 int host_params_init(HostParams &hp, size_t n, size_t nprimes);
 DevParams to_dev_params(const HostParams &hp);
+bool host_known_prime(uint32_t q);  // one of the tabulated 27-/30-bit primes (parameters.c:129-174)
 
 size_t bitrev(size_t x, size_t nbits);
 void host_index_map(const HostParams &hp, std::vector<uint16_t> &map, std::vector<uint16_t> &inv);

@@ -23,6 +23,7 @@ struct DevParams
     uint32_t inv_n[kMaxPrimes];    // n^-1 mod q            (intt.c:230-420 constants)
     uint32_t inv_n_sh[kMaxPrimes]; // floor(inv_n * 2^32 / q)
     double scale;                  // CKKS scale (decode divides by it)
+    uint32_t num_cus;              // compute units of the device (launch geometry of the chain kernels)
 };
 
 // Device-resident read-only tables (pointers into one HBM slab owned by the context).
@@ -36,7 +37,20 @@ struct DevTables
     const uint32_t *pk1;       // [np][n][2] (pk1, shoup)          asym
     const uint32_t *intt_rw;   // [np][n][2] (psi^-bitrev(h+g), shoup) indexed h + g (intt.c:26-58)
     const uint16_t *index_map; // [n] forward index map (decode slot pick)
+    const uint16_t *gather_map; // [n] encoder gather: LDS position (sv_slot) of the value that feeds point k
 };
+
+// LDS position of values[i] in the encoder's staging array.  Thread t gathers, for each e, the value
+// feeding point 16t + e; over the 32 lanes of an LDS lane group those indices are i0 + 2^(logn-10) * h
+// with 32 distinct h (the index map is a discrete log base 3 modulo 2n, and the lanes step the argument
+// by a multiple of 2^(logn-8)), i.e. only 32 / 2^(logn-10) banks of a linear array: a 4-way conflict at
+// n = 4096, 16-way at n = 16384.  Rotating the index right by logn-10 bits puts h into the bank bits.
+constexpr uint32_t sv_slot(uint32_t i, uint32_t logn)
+{
+    const uint32_t s = logn - 10;
+    return ((i >> s) & 31u) | ((i & ((1u << s) - 1u)) << 5) | ((i >> (s + 5)) << (s + 5));
+}
+
 
 enum Mode : int
 {

@@ -573,6 +573,37 @@ def test_encode_only_config5(env):
             assert (got[b, j] == o.ntt(o.reduce_pte(m, j), j)).all()
 
 
+def test_encode_coefficient_of_exactly_2_pow_63(env):
+    """A coefficient of exactly +-2^63 is NOT an overflow for the reference (it rejects only
+    |coeff| > 2^63, ckks_common.c:195) and its build converts +2^63 to INT64_MIN: a constant vector
+    of 2^38 at scale 2^25 produces exactly that in coefficient 0 (all other coefficients 0)."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = 4096, 3
+    o = Oracle(n, npr)
+    ctx = env["pkg"].Context(n, npr)
+    rows = np.stack([np.full(n // 2, s * 2.0 ** 38, dtype=np.float32) for s in (1.0, -1.0, 0.5, 2.0)])
+    out = torch.zeros((4, n), dtype=torch.int64, device=env["dev"])
+    st = torch.zeros(4, dtype=torch.uint8, device=env["dev"])
+    ctx.encode(dev_t(env, rows), out, st)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b in range(4):
+        ok, m = o.encode(rows[b])
+        assert bool(st[b]) == ok, b
+        if ok:
+            assert (got[b] == m).all(), b
+    assert list(st.cpu().numpy()) == [1, 1, 1, 0]
+    assert got[0, 0] == -2 ** 63 and got[1, 0] == -2 ** 63 and got[2, 0] == 2 ** 62
+    res = torch.zeros((4, npr, n), dtype=torch.int32, device=env["dev"])
+    ctx.encode_ntt(dev_t(env, rows), res)
+    torch.cuda.synchronize()
+    for b in range(3):
+        ok, m = o.encode(rows[b])
+        for j in range(npr):
+            assert (host_u32(res[b, j]) == o.ntt(o.reduce_pte(m, j), j)).all(), (b, j)
+
+
 @pytest.mark.parametrize("n,npr", [(4096, 3), (1024, 1)])
 def test_magnitude_classes_through_every_path(env, n, npr):
     """The encoder has a wave-uniform fast path for coefficients below 2^31 - 64 (one-instruction
@@ -698,11 +729,30 @@ def test_overflow_reports_failed_plaintexts(env):
 
 
 # --------------------------------------------------------------------------- full-size properties
+def _compare_all_with_oracle(c0, c1, oracle_chunk, B, chunk=4096):
+    """EVERY ciphertext of a full batch against the threaded oracle, chunk by chunk (bounded host
+    memory): exact element-wise equality of the c0 and c1 records."""
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        ok, e0, e1 = oracle_chunk(lo, hi)
+        assert ok
+        g0 = host_u32(c0[lo:hi])
+        assert np.array_equal(g0, e0), f"c0 differs in ciphertexts [{lo},{hi})"
+        del g0, e0
+        if c1 is not None:
+            g1 = host_u32(c1[lo:hi])
+            assert np.array_equal(g1, e1), f"c1 differs in ciphertexts [{lo},{hi})"
+            del g1
+        del e1
+
+
 def test_full_size_properties_config2(env):
     """BASELINE config 2 shape (n=4096, 3 primes) at a large batch: (a) the reference's own
     round-trip criterion c0 + c1*NTT(s) == NTT(m+e) exactly (ckks_tests_common.c:206) evaluated
     on the GPU outputs for EVERY ciphertext; (b) oracle spot checks on scattered records;
-    (c) determinism: a second run gives identical bytes."""
+    (c) determinism: a second run gives identical bytes; (d) EXHAUSTIVE parity: all B ciphertexts
+    (c0 and c1, every coefficient) equal the threaded oracle's."""
+    from oracle import pyoracle
     from oracle.pyoracle import Oracle
     torch = env["torch"]
     n, npr = 4096, 3
@@ -737,20 +787,23 @@ def test_full_size_properties_config2(env):
     torch.cuda.synchronize()
     assert bool((dec == ntt_pte[:, 0, :]).all())
     assert float((dvals - dv).abs().max()) < 0.1          # ckks_tests_common.c:132,228
-    for b in (0, 1, 63, 64, B // 2 + 17, B - 1):
-        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
-        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b
     d0 = torch.zeros_like(c0)
     d1 = torch.zeros_like(c0)
     ctx.encrypt_sym(dv, dss, dsd, d0, d1)
     torch.cuda.synchronize()
     assert bool((d0 == c0).all()) and bool((d1 == c1).all())
+    del d0, d1, dec, dvals, ntt_pte
+    nt = pyoracle.host_threads()
+    _compare_all_with_oracle(c0, c1, lambda lo, hi: o.encrypt_sym_batch(vals[lo:hi], ss[lo:hi], sd[lo:hi], sk,
+                                                                        nthreads=nt), B)
 
 
 def test_full_size_properties_config4(env):
     """BASELINE config 4 shape at its per-GPU batch (n=16384, 6 primes, 32768 ciphertexts = 24 GiB
-    of output): the exact round-trip criterion through the on-GPU verifier for every ciphertext
-    (first and last prime), canonical ranges, oracle spot checks."""
+    of output), every plaintext distinct: the exact round-trip criterion through the on-GPU verifier
+    for every ciphertext (first and last prime), canonical ranges, and exact parity with the threaded
+    oracle on 2 304 ciphertexts (the first 1 024, the last 1 024 and a stride through the rest)."""
+    from oracle import pyoracle
     from oracle.pyoracle import Oracle
     torch = env["torch"]
     n, npr = 16384, 6
@@ -759,8 +812,7 @@ def test_full_size_properties_config4(env):
     sk = V.secret_key(n)
     ctx.set_secret_key(sk)
     o = Oracle(n, npr)
-    base = V.bench_values(1024, n)
-    vals = np.tile(base, (B // 1024, 1))                 # seeds differ per ciphertext
+    vals = V.bench_values(B, n)                          # B distinct plaintexts (1 GiB)
     ss, sd = V.bench_seeds(B)
     dv, dss, dsd = dev_t(env, vals), dev_t(env, ss), dev_t(env, sd)
     c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
@@ -778,14 +830,23 @@ def test_full_size_properties_config4(env):
         assert bool((dec == ntt_pte[:, j, :]).all()), j
         for t in (c0, c1):
             assert int(t[:, j, :].max()) < q and int(t[:, j, :].min()) >= 0
-    for b in (0, 65, B - 1):
-        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
-        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b
+    del dec, ntt_pte
+    nt = pyoracle.host_threads()
+    k = min(1024, B)
+    picks = sorted(set(list(range(k)) + list(range(B - k, B)) + list(range(k, B - k, max(1, (B - 2 * k) // 256)))))
+    for lo in range(0, len(picks), 256):
+        idx = np.array(picks[lo:lo + 256])
+        ok, e0, e1 = o.encrypt_sym_batch(vals[idx], ss[idx], sd[idx], sk, nthreads=nt)
+        assert ok
+        ti = torch.from_numpy(idx).to(env["dev"])
+        assert np.array_equal(host_u32(c0[ti]), e0), f"c0 differs near ciphertext {idx[0]}"
+        assert np.array_equal(host_u32(c1[ti]), e1), f"c1 differs near ciphertext {idx[0]}"
 
 
 def test_full_size_properties_config3(env):
     """BASELINE config 3 (public-key, n=4096, 3 primes) at batch 65536: canonical ranges,
-    determinism, oracle spot checks across the batch."""
+    determinism, and EXHAUSTIVE parity -- all B ciphertexts equal the threaded oracle's."""
+    from oracle import pyoracle
     from oracle.pyoracle import Oracle
     torch = env["torch"]
     n, npr = 4096, 3
@@ -807,13 +868,53 @@ def test_full_size_properties_config3(env):
     for j in range(npr):
         for t in (c0, c1):
             assert int(t[:, j, :].max()) < o.q[j] and int(t[:, j, :].min()) >= 0
-    for b in (0, 1, 63, 64, 4097, B // 2 + 17, B - 1):
-        r = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
-        assert (host_u32(c0[b]) == r["c0"]).all() and (host_u32(c1[b]) == r["c1"]).all(), b
     d0, d1 = torch.zeros_like(c0), torch.zeros_like(c0)
     ctx.encrypt_asym(dv, dsd, d0, d1)
     torch.cuda.synchronize()
     assert bool((d0 == c0).all()) and bool((d1 == c1).all())
+    del d0, d1
+    nt = pyoracle.host_threads()
+    _compare_all_with_oracle(c0, c1, lambda lo, hi: o.encrypt_asym_batch(vals[lo:hi], sd[lo:hi], pk0, pk1,
+                                                                         nthreads=nt), B)
+
+
+def test_full_size_encode_only_config5(env):
+    """BASELINE config 5 at its full batch (n=4096, 3 primes, encode + RNS + NTT, 1 048 576
+    plaintexts = 48 GiB of output, all distinct): canonical ranges for every record, and exact parity
+    with the threaded oracle on 131 072 + 2 048 of them (the first 65 536, the last 65 536, a stride)."""
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = 4096, 3
+    B = int(os.environ.get("SE_TEST_FULL_B5", "1048576"))
+    ctx = env["pkg"].Context(n, npr)
+    o = Oracle(n, npr)
+    import bench
+    dv = bench.bench_values_device(B, n, env["dev"])
+    out = torch.empty((B, npr, n), dtype=torch.int32, device=env["dev"])
+    status = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encode_ntt(dv, out, status=status)
+    torch.cuda.synchronize()
+    assert bool(status.all())
+    step = 65536
+    for lo in range(0, B, step):
+        blk = out[lo:lo + step]
+        for j in range(npr):
+            assert int(blk[:, j, :].max()) < o.q[j] and int(blk[:, j, :].min()) >= 0
+    nt = pyoracle.host_threads()
+    k = min(65536, B // 2)
+    spans = [(0, k), (B - k, B)]
+    for lo, hi in spans:
+        for a in range(lo, hi, 8192):
+            b = min(hi, a + 8192)
+            ok, e = o.encode_ntt_batch(V.bench_values(b - a, n, first=a), nthreads=nt)
+            assert ok and np.array_equal(host_u32(out[a:b]), e), f"records [{a},{b}) differ"
+    idx = np.arange(k, B - k, max(1, (B - 2 * k) // 2048))[:2048]
+    if idx.size:
+        vals = np.concatenate([V.bench_values(1, n, first=int(i)) for i in idx])
+        ok, e = o.encode_ntt_batch(vals, nthreads=nt)
+        ti = torch.from_numpy(idx).to(env["dev"])
+        assert ok and np.array_equal(host_u32(out[ti]), e)
 
 
 # --------------------------------------------------------------------------- reference API layer
@@ -953,3 +1054,81 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
             first = h
     assert kv["failed"] == "0"
     assert kv["first"] == "%016x" % first and kv["all"] == "%016x" % h
+
+
+# --------------------------------------------------------------------------- device word arithmetic
+@pytest.mark.parametrize("shape,prime", [((1024, 1), 0), ((4096, 3), 0), ((4096, 3), 2), ((16384, 6), 5)])
+def test_device_word_arithmetic_kats(env, golden, shape, prime):
+    """The reference's own Barrett / mul_mod / add / neg edge vectors (device/test/modulo_tests.c:78-179,
+    uintmodarith_tests.c:96-192, tests/golden/ref_kats.json) pushed through the DEVICE inlines of
+    kernels/modarith.cuh (se_amd_word_ops_device), plus MAX_ZZ-class and full-range 64-bit operands
+    against exact integer arithmetic, and both butterflies against their definitions."""
+    n, npr = shape
+    ctx = env["pkg"].Context(n, npr)
+    q = ctx.moduli()[prime]
+    k = golden["kats"]
+    MAX = 0xFFFFFFFF
+    u64 = lambda xs: np.array(xs, dtype=np.uint64)
+
+    rows = [r for r in k["barrett32"] if r[0] == q]
+    if rows:
+        assert list(ctx.word_ops(prime, 0, u64([r[1] for r in rows]))) == [r[2] for r in rows]
+    rows = [r for r in k["barrett64"] if r[0] == q]
+    if rows:
+        assert list(ctx.word_ops(prime, 1, u64([(r[1] << 32) | r[2] for r in rows]))) == [r[3] for r in rows]
+    rows = [r for r in k["mul_mod"] if r[0] == q]
+    if rows:
+        a, b, e = u64([r[1] for r in rows]), u64([r[2] for r in rows]), [r[3] for r in rows]
+        assert list(ctx.word_ops(prime, 2, a, b)) == e
+    # generic cases of uintmodarith_tests.c:96-140, parametrised on q
+    add = [(0, 0, 0), (0, 1, 1), (0, q, 0), (1, q, 1), (1, q - 1, 0), (q, q - 2, q - 2), (q - 1, q - 1, q - 2),
+           (0, 2 * q - 2, q - 2), (q - 10, q, q - 10), (q + 10, q - 12, q - 2)]
+    assert list(ctx.word_ops(prime, 4, u64([r[0] for r in add]), u64([r[1] for r in add]))) == [r[2] for r in add]
+    neg = [(0, 0), (1, q - 1), (q - 1, 1), (q, 0), (10, q - 10), (q - 10, 10)]
+    assert list(ctx.word_ops(prime, 5, u64([r[0] for r in neg]))) == [r[1] for r in neg]
+    mul = [(0, 0, 0), (1, 1, 1), (1, q, 0), (q + 1, 1, 1), (q - 1, 1, q - 1), (0, 12345, 0), (1, MAX, MAX % q),
+           (1, 12345, 12345 % q), (MAX, MAX, MAX * MAX % q), (q - 1, q - 1, 1)]
+    assert list(ctx.word_ops(prime, 2, u64([r[0] for r in mul]), u64([r[1] for r in mul]))) == [r[2] for r in mul]
+
+    rng = np.random.default_rng(q)
+    # 32-bit Barrett over the whole input range incl. the rejection bound neighbourhood
+    x32 = np.concatenate([rng.integers(0, 2 ** 32, 4096, dtype=np.uint64),
+                          u64([0, 1, q - 1, q, q + 1, 2 * q - 1, 2 * q, 3 * q, 4 * q - 1, MAX - 1, MAX,
+                               MAX - MAX % q - 1, MAX - MAX % q - 2])])
+    x32 = x32[x32 <= MAX]
+    assert (ctx.word_ops(prime, 0, x32) == (x32 % np.uint64(q)).astype(np.uint32)).all()
+    # 64-bit Barrett: full-range operands (the "remainder estimate is in [0, 2q)" claim of modarith.cuh)
+    edge = [0, 1, q, q * q, q * q - 1, (q - 1) * (q - 1), 2 ** 63 - 1, 2 ** 63, 2 ** 63 + 1, 2 ** 64 - 1,
+            2 ** 64 - q, (2 ** 64 // q) * q, (2 ** 64 // q) * q - 1, MAX * MAX, MAX << 32, (MAX << 32) | MAX]
+    x64 = np.concatenate([rng.integers(0, 2 ** 64, 8192, dtype=np.uint64), u64(edge)])
+    exp = np.array([int(v) % q for v in x64], dtype=np.uint32)
+    assert (ctx.word_ops(prime, 1, x64) == exp).all()
+    # Shoup product: a may be ANY 32-bit word (lazy NTT values < 4q, raw PRNG words), b < q
+    a = np.concatenate([rng.integers(0, 2 ** 32, 4096, dtype=np.uint64), u64([0, 1, q - 1, q, 2 * q, 4 * q - 1, MAX])])
+    b = np.concatenate([rng.integers(0, q, 4096, dtype=np.uint64), u64([0, 1, q - 1, q - 1, q - 1, q - 1, q - 1])])
+    exp = np.array([int(x) * int(y) % q for x, y in zip(a, b)], dtype=np.uint32)
+    assert (ctx.word_ops(prime, 3, a, b) == exp).all()
+    a, b = rng.integers(0, q + 1, 4096, dtype=np.uint64), rng.integers(0, q + 1, 4096, dtype=np.uint64)
+    assert (ctx.word_ops(prime, 6, a, b) == ((a + np.uint64(2 * q) - b) % np.uint64(q)).astype(np.uint32)).all()
+    # signed reduction incl. the reference's non-canonical q for negative multiples (ckks_common.c:234)
+    m = np.concatenate([rng.integers(-2 ** 63, 2 ** 63, 4096, dtype=np.int64),
+                        np.array([0, -1, 1, -q, q, -2 * q, -(2 ** 63) + 1, 2 ** 63 - 1, -q * q, -(2 ** 31), 2 ** 31],
+                                 dtype=np.int64)])
+    exp = []
+    for v in m:
+        r = abs(int(v)) % q
+        exp.append(q - r if v < 0 else r)
+    assert list(ctx.word_ops(prime, 7, m.view(np.uint64))) == exp
+    x = rng.integers(0, 4 * q, 4096, dtype=np.uint64)
+    assert (ctx.word_ops(prime, 8, x) == (x % np.uint64(q)).astype(np.uint32)).all()
+    # butterflies on lazy operands (< 4q) against their definitions
+    X, Y = rng.integers(0, 4 * q, 4096, dtype=np.uint64), rng.integers(0, 4 * q, 4096, dtype=np.uint64)
+    W = rng.integers(1, q, 4096, dtype=np.uint64)
+    t = np.array([int(y) * int(w) % q for y, w in zip(Y, W)], dtype=np.uint64)
+    assert (ctx.word_ops(prime, 9, X, Y, W) == ((X + t) % np.uint64(q)).astype(np.uint32)).all()
+    assert (ctx.word_ops(prime, 10, X, Y, W) == ((X + np.uint64(4 * q) - t) % np.uint64(q)).astype(np.uint32)).all()
+    X, Y = rng.integers(0, 2 * q, 4096, dtype=np.uint64), rng.integers(0, 2 * q, 4096, dtype=np.uint64)
+    assert (ctx.word_ops(prime, 11, X, Y, W) == ((X + Y) % np.uint64(q)).astype(np.uint32)).all()
+    d = np.array([(int(x) - int(y)) * int(w) % q for x, y, w in zip(X, Y, W)], dtype=np.uint32)
+    assert (ctx.word_ops(prime, 12, X, Y, W) == d).all()
+    ctx.close()

@@ -44,17 +44,27 @@ def _worker(rank, world, port, total, q):
     ss, sd = V.bench_seeds(hi - lo, first=lo)
     ok, c0, c1 = o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=1)
     rec = torch.from_numpy(np.stack([c0, c1], axis=1).view(np.int32))
-    out = gather_records(rec, dist, dst=0, chunk_records=2)
+    # tiny messages (2 records each) force the chunked path; the root's own block is produced IN PLACE
+    # in its slice of the gathered slab on the second pass (no local copy then)
+    out = gather_records(rec, dist, dst=0, chunk_bytes=2 * 2 * npr * n * 4)
+    sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
     if rank == 0:
+        first = out.clone()
+        slab = torch.zeros_like(out)
+        slab[lo:hi] = rec
+        out2 = gather_records(slab[lo:hi], dist, dst=0, out=slab, sizes=sizes)
+        assert out2.data_ptr() == slab.data_ptr() and bool((out2 == first).all())
         q.put(out.numpy().view(np.uint32))
+    else:
+        gather_records(rec, dist, dst=0, sizes=sizes)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_gather_matches_single_process():
+@pytest.mark.parametrize("total,world", [(7, 2), (1, 2), (5, 3)])   # uneven: 4+3; one EMPTY shard; 2+2+1
+def test_two_rank_gloo_gather_matches_single_process(total, world):
     import torch.multiprocessing as mp
     from oracle.pyoracle import Oracle
-    total, world = 7, 2          # uneven shards: 4 + 3
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -78,23 +88,73 @@ def test_two_rank_gloo_gather_matches_single_process():
 def test_bench_contract_constants():
     """bench.py's workload table against SURVEY.md 8(d): algorithmic bytes per unit, batch sizes of
     the BASELINE configs, and the JSON keys the driver parses (static checks: no GPU here)."""
-    import ast
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "bench.py")).read()
-    tree = ast.parse(src)
-    wl = None
-    for node in tree.body:
-        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "WORKLOADS":
-            wl = eval(compile(ast.Expression(node.value), "bench.py", "eval"))
-    assert wl is not None
-    assert wl["c2"] == (4096, 3, "sym", 65536, 106624)
-    assert wl["c3"] == (4096, 3, "asym", 65536, 106560)
-    assert wl["c4"] == (16384, 6, "sym", 32768, 819328)
-    assert wl["c5"] == (4096, 3, "encode", 262144, 57344)
-    assert wl["c1"] == (1024, 1, "sym", 1, 10368)
+    import bench
+    wl = bench.WORKLOADS
+    assert wl["c2"] == (4096, 3, "sym", 65536) and bench.bytes_per_unit("sym", 4096, 3) == 106624
+    assert wl["c3"] == (4096, 3, "asym", 65536) and bench.bytes_per_unit("asym", 4096, 3) == 106560
+    assert wl["c4"] == (16384, 6, "sym", 32768) and bench.bytes_per_unit("sym", 16384, 6) == 819328
+    assert wl["c5"] == (4096, 3, "encode", 1048576) and bench.bytes_per_unit("encode", 4096, 3) == 57344
+    assert wl["c1"] == (1024, 1, "sym", 1) and bench.bytes_per_unit("sym", 1024, 1) == 10368
+    # every kernel's own bytes: the symmetric fused step reads a back once, the uniform sampler only writes it
+    kb = bench.kernel_bytes_per_unit("sym", 4096, 3)
+    assert kb["uniform"] == 64 + 49152 and kb["encode_encrypt"] == 8192 + 4096 + 2 * 49152
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"',
                 '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"',
                 '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"',
-                '"cores"', '"kind"', '"sample"'):
+                '"cores"', '"kind"', '"sample"', '"other_configs"', '"valu"'):
         assert key in src, key
+    assert len(bench.kernel_source_hash()) == 16
+
+
+def _run_bench(world, extra, tmp_path):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SE_BENCH_STUB="stub_context", PYTHONPATH=os.path.join(root, "tests"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", str(world)] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout        # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_rank_logic_two_ranks_gloo(tmp_path):
+    """bench.py itself under torch.distributed.run with 2 ranks (gloo, CPU tensors, the oracle-backed
+    stub context of tests/stub_context.py in place of the library): rank r encrypts block r of the batch
+    index (`first = rank * B`), the line reports n_gpus = 2 with the whole-job rate, and the gathered
+    slab on rank 0 is bit-identical to the single-process order (checked inside the run)."""
+    d = _run_bench(2, ["--steps", "2", "--warmup", "1", "--workload", "c1", "--batch", "3", "--others", "none"],
+                   tmp_path)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["batch_per_gpu"] == 3 and d["config"]["global_batch"] == 6
+    assert abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6     # units of ALL ranks / max time
+    assert d["cpu_baseline"] is None and d["vs_baseline"] is None and d["higher_is_better"] is True
+    g = d["gather"]
+    assert g["form"] == "full" and g["bytes_into_root"] == 2 * 3 * 4 * 1024 and g["value_with_gather"] < d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None
+
+
+def test_bench_gathered_slab_is_single_process_order(tmp_path):
+    """The same run with SE_BENCH_DUMP: rank 0 writes the gathered c0/c1 slabs; they equal the oracle's
+    records for batch indices 0 .. world*B-1 in order."""
+    from oracle.pyoracle import Oracle
+    dump = tmp_path / "slab.npz"
+    os.environ["SE_BENCH_DUMP"] = str(dump)
+    try:
+        _run_bench(2, ["--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "2", "--others", "none"],
+                   tmp_path)
+    finally:
+        os.environ.pop("SE_BENCH_DUMP", None)
+    got = np.load(dump)
+    n, npr, total = 1024, 1, 4
+    ok, c0, c1 = Oracle(n, npr).encrypt_sym_batch(V.bench_values(total, n), *V.bench_seeds(total),
+                                                  V.secret_key(n), nthreads=1)
+    assert (got["c0"].view(np.uint32) == c0).all() and (got["c1"].view(np.uint32) == c1).all()
