@@ -169,6 +169,16 @@ int se_amd_load_keys_from_dir(se_amd_ctx *ctx, const char *dir, int want_pk);
 int se_amd_gen_public_key(se_amd_ctx *ctx, const uint8_t *sk_packed, const uint8_t *pk_seed,
                           const uint8_t *ep_seed, uint32_t *pk0, uint32_t *pk1);
 
+/* K key pairs in one launch chain (host pointers).  Secret key k: the sample branch
+ * of ckks_setup_s (ckks_sym.c:162-179) = sample_small_poly_ternary_prng_96 from PRNG(sk_seeds[k]) at
+ * counter 0, 2-bit packed (sk_<n>.dat format) -- or sk_in[k] when sk_in != NULL (sk_seeds may then be
+ * NULL).  Public key k: gen_pk per prime exactly as se_amd_gen_public_key, from pk_seeds[k] / ep_seeds[k].
+ * Seeds [K][64]; sk_in / sk_out [K][n/4] (sk_out may be NULL); pk0, pk1 [K][np][n] uint32 out.  The keys
+ * installed in the context are not touched. */
+int se_amd_gen_keys_batch(se_amd_ctx *ctx, size_t K, const uint8_t *sk_in, const uint8_t *sk_seeds,
+                          const uint8_t *pk_seeds, const uint8_t *ep_seeds, uint8_t *sk_out, uint32_t *pk0,
+                          uint32_t *pk1);
+
 /* Whole path, device pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
  * Optional outputs may be NULL: ntt_pte [B][np][n] = NTT(m+e mod q_j); pte [B][n] int64;
  * status [B] bytes (1 ok / 0 encode overflow).  Internal scratch is grown on demand (not

@@ -423,6 +423,9 @@ class Reference:
             L.refh_decrypt.argtypes = [C.c_void_p, C.c_size_t, u32p, u32p, u32p, u32p]
             L.refh_decode.argtypes = [C.c_void_p, C.c_size_t, u32p, C.c_size_t, f32p]
             L.refh_print_to_file.argtypes = [C.c_char_p, C.c_char_p, u32p, C.c_size_t, f32p, C.c_size_t]
+            L.refh_api_encrypt_print.restype = C.c_long
+            L.refh_api_encrypt_print.argtypes = [C.c_size_t, C.c_size_t, C.c_int, f32p, C.c_size_t, u8p, u8p,
+                                                 C.c_char_p]
             L.refh_encrypt_asym_batch.restype = C.c_int
             L.refh_encrypt_asym_batch.argtypes = [C.c_size_t, C.c_size_t, f32p, C.c_size_t, u8p, u32p,
                                                   u32p, u32p, u32p, C.c_int]
@@ -667,3 +670,13 @@ class Reference:
         out = np.zeros((B, nprimes, n), dtype=np.uint32) if keep else None
         L.refh_encode_ntt_batch(n, nprimes, _p(v, f32p), B, _p(out, u32p), nthreads)
         return out
+
+    @classmethod
+    def api_print_lines(cls, n, nprimes, asym, values, share_seed, seed, path):
+        """se_encrypt_seeded(print=true) of the reference: the "c0: " / "c1: " lines it prints."""
+        L = cls.lib()
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        ok = L.refh_api_encrypt_print(n, nprimes, 1 if asym else 0, _p(v, f32p), v.nbytes, _p(_seed(share_seed), u8p),
+                                      _p(_seed(seed), u8p), path.encode())
+        assert ok
+        return [l for l in open(path).read().splitlines(True) if l.startswith(("c0: ", "c1: "))]

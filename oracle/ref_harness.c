@@ -393,6 +393,28 @@ long refh_api_encrypt(size_t n, size_t nprimes, int asym, const float *v, size_t
     return ok ? (long)g_sink_len : -1;
 }
 
+/* the same call with print = true; the library's stdout (incl. its unconditional setup chatter, T2)
+ * goes to `path`, the caller filters the "c0: " / "c1: " lines (seal_embedded.c:160-163) */
+long refh_api_encrypt_print(size_t n, size_t nprimes, int asym, const float *v, size_t vlen_bytes,
+                            const uint8_t *share_seed, const uint8_t *seed, const char *path)
+{
+    uint8_t s1[64], s2[64];
+    memcpy(s1, share_seed, 64);
+    memcpy(s2, seed, 64);
+    fflush(stdout);
+    int saved = dup(1);
+    int fd    = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    dup2(fd, 1);
+    close(fd);
+    SE_PARMS *sp = se_setup(n, nprimes, 0.0, asym ? SE_ASYM_ENCR : SE_SYM_ENCR);
+    bool ok      = se_encrypt_seeded(s1, s2, NULL, (void *)v, vlen_bytes, true, sp);
+    se_cleanup(sp);
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
+    return ok ? 1 : 0;
+}
+
 /* --- timed CPU baseline over the reference itself: bench_sym.c:96-130 region ---------------
  * (encode + ckks_sym_init + per-prime ckks_encode_encrypt_sym; keys resident), one reference
  * instance per thread over a contiguous shard of the batch. */

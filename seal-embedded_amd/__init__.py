@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "se_cleanup", "se_encrypt_batch",
     "se_amd_create", "se_amd_destroy", "se_amd_degree", "se_amd_nprimes", "se_amd_scale",
     "se_amd_moduli", "se_amd_index_map", "se_amd_set_secret_key", "se_amd_set_public_key",
-    "se_amd_load_keys_from_dir", "se_amd_gen_public_key", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device", "se_amd_encrypt_sym_seeded_device",
+    "se_amd_load_keys_from_dir", "se_amd_gen_public_key", "se_amd_gen_keys_batch", "se_amd_encrypt_sym_device", "se_amd_encrypt_asym_device", "se_amd_encrypt_sym_seeded_device",
     "se_amd_expand_c1_device",
     "se_amd_encode_ntt_device", "se_amd_encrypt_sym_host", "se_amd_encrypt_asym_host",
     "se_amd_encode_device", "se_amd_ntt_device", "se_amd_intt_device", "se_amd_decrypt_decode_device", "se_amd_prng_blocks_device",
@@ -83,6 +83,7 @@ def lib():
     L.se_amd_set_public_key.argtypes = [vp, vp, vp]
     L.se_amd_load_keys_from_dir.argtypes = [vp, C.c_char_p, i32]
     L.se_amd_gen_public_key.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.se_amd_gen_keys_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_sym_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_asym_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.se_amd_encrypt_sym_seeded_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
@@ -218,6 +219,21 @@ class Context:
         _check(self.L.se_amd_gen_public_key(self.h, _ptr(sk), _ptr(s1), _ptr(s2), _ptr(pk0),
                                             _ptr(pk1)), "se_amd_gen_public_key")
         return pk0, pk1
+
+    def gen_keys_batch(self, pk_seeds, ep_seeds, sk_seeds=None, sk_in=None):
+        """K key pairs in one launch chain: (sk [K][n/4] uint8, pk0, pk1 [K][np][n] uint32)."""
+        import numpy as np
+        pks = np.ascontiguousarray(pk_seeds, dtype=np.uint8).reshape(-1, 64)
+        K = pks.shape[0]
+        eps = np.ascontiguousarray(ep_seeds, dtype=np.uint8).reshape(K, 64)
+        sks = None if sk_seeds is None else np.ascontiguousarray(sk_seeds, dtype=np.uint8).reshape(K, 64)
+        ski = None if sk_in is None else np.ascontiguousarray(sk_in, dtype=np.uint8).reshape(K, self.n // 4)
+        sk = np.zeros((K, self.n // 4), dtype=np.uint8)
+        pk0 = np.zeros((K, self.np, self.n), dtype=np.uint32)
+        pk1 = np.zeros_like(pk0)
+        _check(self.L.se_amd_gen_keys_batch(self.h, K, _ptr(ski), _ptr(sks), _ptr(pks), _ptr(eps), _ptr(sk),
+                                            _ptr(pk0), _ptr(pk1)), "se_amd_gen_keys_batch")
+        return sk, pk0, pk1
 
     def load_keys_from_dir(self, path, want_pk=False):
         _check(self.L.se_amd_load_keys_from_dir(self.h, path.encode(), 1 if want_pk else 0),

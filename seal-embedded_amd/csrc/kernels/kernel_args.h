@@ -105,13 +105,16 @@ struct FftArgs
 };
 struct LowerSymArgs
 {
-    const uint8_t *s_small;  // [n/4] 2-bit packed secret key (shared by the batch)
+    const uint8_t *s_small;  // 2-bit packed secret key(s): polynomial b uses s_small + b * s_stride bytes
     const int64_t *pte;      // [count][n] m + e, or NULL ...
     const int8_t *ep;        // ... then [count][n] small error (gen_pk)
-    const uint32_t *a;       // [count][n] uniform polynomial of this prime (NTT domain)
-    uint32_t *c0, *ntt_pte;  // [count][n]
+    const uint32_t *a;       // uniform polynomial of this prime (NTT domain): a + b * a_stride
+    uint32_t *c0, *ntt_pte;  // c0 + b * c0_stride; ntt_pte [count][n]
     uint32_t *s_save;        // optional [count][n]
     int j;
+    uint32_t s_stride;       // bytes between the keys of consecutive polynomials (0 = one shared key)
+    uint32_t a_stride;       // elements between consecutive polynomials of `a`  (0 = n)
+    uint32_t c0_stride;      // elements between consecutive polynomials of `c0` (0 = n)
 };
 struct LowerAsymArgs
 {
@@ -129,6 +132,7 @@ hipError_t launch_reduce_poly(const DevParams &, int j, const int64_t *pte, cons
 hipError_t launch_word_ops(const DevParams &, int j, int op, const uint64_t *a, const uint64_t *b,
                            const uint64_t *c, uint32_t *out, size_t count, hipStream_t);
 hipError_t launch_add_small(int64_t *m, const int8_t *e, size_t total, hipStream_t);
+hipError_t launch_pack_ternary(const int8_t *codes, uint8_t *packed, size_t total_bytes, hipStream_t);
 hipError_t launch_expand_ternary(const uint8_t *packed, uint32_t *out, uint32_t q, uint32_t n, hipStream_t);
 hipError_t launch_lower_sym_prime(const DevParams &, const DevTables &, const LowerSymArgs &, size_t count,
                                   hipStream_t);

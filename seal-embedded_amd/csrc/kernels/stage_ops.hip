@@ -199,6 +199,24 @@ hipError_t launch_add_small(int64_t *m, const int8_t *e, size_t total, hipStream
     return hipGetLastError();
 }
 
+// set_small_poly_idx packing (sample.c:61-87): four 2-bit codes per byte, first coefficient in the
+// two MOST significant bits
+__global__ void k_pack_ternary(const int8_t *codes, uint8_t *packed, size_t total_bytes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_bytes) return;
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(codes + 4 * i);
+    packed[i] = (uint8_t)(((w & 3u) << 6) | (((w >> 8) & 3u) << 4) | (((w >> 16) & 3u) << 2) | ((w >> 24) & 3u));
+}
+
+hipError_t launch_pack_ternary(const int8_t *codes, uint8_t *packed, size_t total_bytes, hipStream_t st)
+{
+    if (total_bytes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_ternary, dim3((unsigned)((total_bytes + 255) / 256)), dim3(256), 0, st, codes,
+                       packed, total_bytes);
+    return hipGetLastError();
+}
+
 __global__ void k_expand_ternary(const uint8_t *packed, uint32_t *out, uint32_t q, uint32_t n)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,17 +249,20 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_lower_sym_prime(De
     const uint32_t q = P.q[j], two_q = q << 1, crh = P.cr_hi[j], crl = P.cr_lo[j];
     const uint32_t *RW = T.ntt_rw + (size_t)2 * N * j;
     const size_t off   = b * N + 16 * t;
+    const uint8_t *key = A.s_small + b * (size_t)A.s_stride;
+    const uint32_t *ap = A.a + b * (size_t)(A.a_stride ? A.a_stride : N) + 16 * t;
+    uint32_t *c0p      = A.c0 + b * (size_t)(A.c0_stride ? A.c0_stride : N) + 16 * t;
 
     uint32_t x[16], c0[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = expand_code(A.s_small, (uint32_t)((e << CTOP) + t), q);
+    for (int e = 0; e < 16; e++) x[e] = expand_code(key, (uint32_t)((e << CTOP) + t), q);
     ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
     if (A.s_save) store16u(A.s_save + off, x);
     {
         uint32_t a[16];
-        load16u(a, A.a + off);
+        load16u(a, ap);
 #pragma unroll
         for (int e = 0; e < 16; e++)
         {
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_lower_sym_prime(De
     // the caller's ntt_pte and c1 buffers may be the same memory (ckks_sym.c:86-88): write order is
     // the host wrapper's business, the kernel only produces the two polynomials
     store16u(A.ntt_pte + off, x);
-    store16u(A.c0 + off, c0);
+    store16u(c0p, c0);
 }
 
 // ------------------------------------------------------------------------------------------

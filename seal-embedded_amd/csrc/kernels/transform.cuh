@@ -136,14 +136,66 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
     });
 }
 
+// First IFFT pass (window 0, stages 0..3) for REAL input (im == +0 everywhere: the CKKS encoder's
+// conjugate-symmetric slot vector, ckks_common.c:148-150).  A butterfly whose two inputs are still real
+// needs 2 adds + 2 multiplies instead of the 10 operations of the complex form:
+//     (u, v) -> (u + v, (u - v) * w)  =  (u + v,  (ar * w.x) + i (ar * w.y)),   ar = u - v
+// Position e of a tile is real before stage b iff its low b bits are zero, so 8 + 4 + 2 + 1 = 15 of
+// the pass's 32 butterflies take the short form.  The general form would compute ar*w.x - (+0)*w.y and
+// ar*w.y + (+0)*w.x: adding or subtracting a zero leaves every NONZERO value bit-identical and can only
+// change the sign of a zero result; a zero's sign never reaches a nonzero value through +, -, * and
+// vanishes in the encoder's final round-to-int64 (and in its |.| overflow test).  So the int64
+// plaintext is bit-identical; the complex-output operators (ifft_inpl) keep the general form.
+template <int LOGN>
+__device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[16],
+                                                const double *__restrict__ W, int t)
+{
+    constexpr int N = 1 << LOGN;
+    static_for<0, 4>([&](auto bc) {
+        constexpr int b      = decltype(bc)::value;
+        constexpr int h      = N >> (b + 1);
+        constexpr int groups = 1 << (3 - b);
+        static_for<0, groups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int idx   = h + ((t << (3 - b)) | g);
+            const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
+            static_for<0, (1 << b)>([&](auto rc) {
+                constexpr int r  = decltype(rc)::value;
+                constexpr int e0 = (g << (b + 1)) | r;
+                constexpr int e1 = e0 | (1 << b);
+                if constexpr (r == 0)
+                {
+                    const double ar = __dsub_rn(re[e0], re[e1]);
+                    re[e0]          = __dadd_rn(re[e0], re[e1]);
+                    re[e1]          = __dmul_rn(ar, w.x);
+                    im[e1]          = __dmul_rn(ar, w.y);
+                }
+                else
+                {
+                    double ar = __dsub_rn(re[e0], re[e1]);
+                    double ai = __dsub_rn(im[e0], im[e1]);
+                    re[e0]    = __dadd_rn(re[e0], re[e1]);
+                    im[e0]    = __dadd_rn(im[e0], im[e1]);
+                    re[e1]    = __dsub_rn(__dmul_rn(ar, w.x), __dmul_rn(ai, w.y));
+                    im[e1]    = __dadd_rn(__dmul_rn(ar, w.y), __dmul_rn(ai, w.x));
+                }
+            });
+        });
+    });
+}
+
 // Whole IFFT: input in tile layout 0 (thread t holds points 16t..16t+15), output in tile layout
 // LOGN-4 (thread t holds points t + (n/16)*e).  `plane` = LDS scratch of XformGeom::SLOTS doubles.
-template <int LOGN>
+// REAL_IN: the imaginary parts of the input are all +0 (im[] need not be initialised except im[0]).
+template <int LOGN, bool REAL_IN = false>
 __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
                                            const double *__restrict__ W, double *plane, int t)
 {
     using G = XformGeom<LOGN>;
-    ifft_pass<LOGN, 0, 0, 4>(re, im, W, t);
+    if constexpr (REAL_IN)
+        ifft_pass0_real<LOGN>(re, im, W, t);
+    else
+        ifft_pass<LOGN, 0, 0, 4>(re, im, W, t);
     redeal<0, 4>(re, plane, t);
     redeal<0, 4>(im, plane, t);
     ifft_pass<LOGN, 4, 0, 4>(re, im, W, t);

@@ -95,6 +95,14 @@ int se_amd_gen_public_key(se_amd_ctx *ctx, const uint8_t *sk_packed, const uint8
     return ctx->c.gen_public_key(sk_packed, pk_seed, ep_seed, pk0, pk1);
 }
 
+int se_amd_gen_keys_batch(se_amd_ctx *ctx, size_t K, const uint8_t *sk_in, const uint8_t *sk_seeds,
+                          const uint8_t *pk_seeds, const uint8_t *ep_seeds, uint8_t *sk_out, uint32_t *pk0,
+                          uint32_t *pk1)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    return ctx->c.gen_keys_batch(K, sk_in, sk_seeds, pk_seeds, ep_seeds, sk_out, pk0, pk1);
+}
+
 static int read_exact(const std::string &path, void *dst, size_t bytes)
 {
     FILE *f = fopen(path.c_str(), "rb");

@@ -357,6 +357,63 @@ int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, co
     return 0;
 }
 
+// Batched key generation: K independent key pairs in one launch chain.
+//   secret key k : ckks_setup_s's sample branch (ckks_sym.c:162-179) = sample_small_poly_ternary_prng_96
+//                  from PRNG(sk_seeds[k]) at counter 0 (sample.c:218-242), 2-bit packed; or sk_in[k]
+//   public key k : gen_pk per prime as device/test/ckks_tests_asym.c:174-208 drives it: ep = n CBD samples
+//                  from PRNG(ep_seeds[k]); per prime the shareable PRNG restarts from pk_seeds[k] at
+//                  counter 0: pk1_j = a_j, pk0_j = -(a_j . NTT(s)) + NTT(ep mod q_j)
+// Launches: 1 ternary sampler + 1 pack + 1 CBD + per prime {uniform sampler, sym-prime kernel} for all K.
+int Context::gen_keys_batch(size_t K, const uint8_t *sk_in, const uint8_t *sk_seeds, const uint8_t *pk_seeds,
+                            const uint8_t *ep_seeds, uint8_t *sk_out, uint32_t *pk0_out, uint32_t *pk1_out)
+{
+    if (K == 0) return 0;
+    if ((!sk_in && !sk_seeds) || !pk_seeds || !ep_seeds || !pk0_out || !pk1_out) return kErrInvalid;
+    std::lock_guard<std::mutex> lk(mu);
+    SEAMD_HIP(hipSetDevice(device));
+    int rc = ensure_scratch(K);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
+    const size_t slab = (size_t)K * np * n;
+    DevTemp seeds, keys, codes, ep, pk0, pk1, tmp;
+    SEAMD_HIP(seeds.alloc(K * 192, true));
+    SEAMD_HIP(keys.alloc(K * (n / 4), true));
+    SEAMD_HIP(codes.alloc((size_t)K * n, true));
+    SEAMD_HIP(ep.alloc((size_t)K * n, true));
+    SEAMD_HIP(pk0.alloc(slab * sizeof(uint32_t)));
+    SEAMD_HIP(pk1.alloc(slab * sizeof(uint32_t)));
+    SEAMD_HIP(tmp.alloc((size_t)K * n * sizeof(uint32_t), true));   // NTT(ep): secret as well
+    uint8_t *d_sk_seeds = seeds.as<uint8_t>(), *d_pk_seeds = d_sk_seeds + K * 64, *d_ep_seeds = d_sk_seeds + K * 128;
+    if (sk_seeds) SEAMD_HIP(hipMemcpy(d_sk_seeds, sk_seeds, K * 64, hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_pk_seeds, pk_seeds, K * 64, hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_ep_seeds, ep_seeds, K * 64, hipMemcpyHostToDevice));
+    if (sk_in)
+        SEAMD_HIP(hipMemcpy(keys.p, sk_in, K * (n / 4), hipMemcpyHostToDevice));
+    else
+    {
+        TernaryArgs ta{d_sk_seeds, codes.as<int8_t>(), nullptr, n, (uint32_t)K, nullptr, (uint32_t)num_cus};
+        SEAMD_HIP(launch_sample_ternary(ta, nullptr));
+        SEAMD_HIP(launch_pack_ternary(codes.as<int8_t>(), keys.as<uint8_t>(), K * (n / 4), nullptr));
+    }
+    CbdArgs ca{d_ep_seeds, nullptr, ep.as<int8_t>(), n / 16, (uint32_t)K};
+    SEAMD_HIP(launch_sample_cbd(ca, nullptr));
+    for (uint32_t j = 0; j < np; j++)
+    {
+        // a_j for every key, counter 0 (gen_pk re-seeds per prime, ckks_asym.c:163), into pk1[:, j]
+        UniformArgs ua{d_pk_seeds, nullptr, nullptr, pk1.as<uint32_t>(), d_rej, rej_cap, (uint32_t)K, j, j + 1, np,
+                       d_spec,     spec_cap, 0,      debug_flags};
+        SEAMD_HIP(launch_sample_uniform(dp, ua, nullptr));
+        LowerSymArgs sa{keys.as<uint8_t>(), nullptr, ep.as<int8_t>(), pk1.as<uint32_t>() + (size_t)j * n,
+                        pk0.as<uint32_t>() + (size_t)j * n, tmp.as<uint32_t>(), nullptr, (int)j, n / 4, np * n, np * n};
+        SEAMD_HIP(launch_lower_sym_prime(dp, dt, sa, K, nullptr));
+    }
+    SEAMD_HIP(hipDeviceSynchronize());
+    if (sk_out) SEAMD_HIP(hipMemcpy(sk_out, keys.p, K * (n / 4), hipMemcpyDeviceToHost));
+    SEAMD_HIP(hipMemcpy(pk0_out, pk0.p, slab * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SEAMD_HIP(hipMemcpy(pk1_out, pk1.p, slab * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 void Context::stage_begin(int stage, hipStream_t st)
 {
     if (!profiling) return;

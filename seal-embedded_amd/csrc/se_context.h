@@ -111,6 +111,9 @@ struct Context
     int set_public_key(const uint32_t *pk0, const uint32_t *pk1);
     int gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, const uint8_t *ep_seed,
                        uint32_t *pk0_out, uint32_t *pk1_out);
+    // K key pairs in one launch chain (host pointers); does not touch the context's installed keys
+    int gen_keys_batch(size_t K, const uint8_t *sk_in, const uint8_t *sk_seeds, const uint8_t *pk_seeds,
+                       const uint8_t *ep_seeds, uint8_t *sk_out, uint32_t *pk0_out, uint32_t *pk1_out);
 
     // public entries: serialised on the context's scratch (begin_call / end_call around *_impl)
     int encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share_seeds,

@@ -671,7 +671,7 @@ void ckks_encode_encrypt_sym(const Parms *parms, const int64_t *conj_vals_int, c
     else
         up(L.i64, conj_vals_int, 8 * n);
     seamd::LowerSymArgs sa{L.packed, ep_small ? nullptr : L.i64, ep_small ? L.i8[0] : nullptr, L.u32[0],
-                           L.u32[1], L.u32[2], L.u32[3], prime_of(parms)};
+                           L.u32[1], L.u32[2], L.u32[3], prime_of(parms), 0, 0, 0};
     LOWER_HIP(seamd::launch_lower_sym_prime(L.c().dp, L.c().dt, sa, 1, nullptr));
     // deliveries in the reference's write order, so that aliased buffers end up the same
     down(c1, L.u32[0], 4 * n);

@@ -68,6 +68,20 @@ def api_digest(n, nprimes, asym, sk, pk0, pk1, q):
     return "%016x" % pyoracle.fnv1a64(out.tobytes())
 
 
+def api_print(n, nprimes, sk):
+    """se_encrypt_seeded(print = true) in a scratch CWD: the lines the reference prints per prime."""
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "adapter_output_data"))
+        sk.tofile(os.path.join(td, "adapter_output_data", f"sk_{n}.dat"))
+        os.chdir(td)
+        try:
+            return Reference.api_print_lines(n, nprimes, False, V.survey_values(n), V.SURVEY_SHARE_SEED,
+                                             V.SURVEY_SEED, os.path.join(td, "out.txt"))
+        finally:
+            os.chdir(cwd)
+
+
 def main():
     pyoracle.build(ref=True)
     assert pyoracle.ref_available(), "needs /root/reference to build oracle/_ref"
@@ -202,6 +216,8 @@ def main():
         # API-level callback stream (reproduces the c1-alias quirk in sym mode)
         d["api_fnv1a64_sym"] = api_digest(n, nprimes, False, sk, None, None, q)
         d["api_fnv1a64_asym"] = api_digest(n, nprimes, True, sk, pk0, pk1, q)
+        if (n, nprimes) in ((1024, 1), (4096, 3)):
+            d["api_print_sym"] = api_print(n, nprimes, sk)
         digests["shapes"][f"{n}x{nprimes}"] = d
         RA.close()
         R.close()

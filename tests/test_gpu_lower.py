@@ -287,8 +287,8 @@ def test_lower_encode_base_contract(env, golden):
     assert not L.ckks_encode_base(C.byref(P), _vp(big), C.c_size_t(n // 2), _vp(imap), None, _vp(conj))
     assert not g["overflow_3e38_ok"]
     x = np.zeros(n, np.complex128)
-    x[imap[:n // 2]] = 3.0e38
-    x[imap[n // 2:]] = 3.0e38
+    x[imap[:n // 2]] = float(big[0])          # the float32 value, widened (ckks_common.c:148)
+    x[imap[n // 2:]] = float(big[0])
     full = o.ifft(x)
     coeff = full.real * (o.p.scale / n)
     bad = int(np.argmax(np.abs(np.where(coeff >= 0, np.floor(coeff + 0.5), np.ceil(coeff - 0.5))) > 2.0 ** 63))

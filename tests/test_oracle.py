@@ -7,6 +7,7 @@
 CPU only; runs in the build container and on the GPU box alike.
 """
 import hashlib
+import os
 import struct
 
 import numpy as np
@@ -317,3 +318,15 @@ def test_batched_driver_matches_single():
     for b in range(B):
         r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
         assert (c0[b] == r["c0"]).all() and (c1[b] == r["c1"]).all()
+
+
+def test_oracle_is_sanitizer_clean():
+    """`make -C oracle sanitize`: the C restatement under AddressSanitizer + UndefinedBehaviorSanitizer,
+    every entry point (incl. the threaded batch drivers, extreme magnitudes, overflow, all five
+    shapes up to 13 primes) driven by oracle/oracle_selftest.c -- SURVEY.md section 5."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "all shapes clean under ASan + UBSan" in r.stdout
