@@ -150,15 +150,8 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     if (status && t == 0) status[b] = (uint8_t)all_ok;
 }
 
-// Build-time variants (A/B experiments, tools/ab_bench.sh):
-//   SEAMD_MHI_LDS  park the high words of the int64 plaintext in LDS across the prime loop (16 VGPRs
-//                  less; only the rare general-magnitude path reads them back)
-//   SEAMD_OCC      waves per SIMD the n <= 4096 symmetric / encode-only kernels are compiled for
-#ifndef SEAMD_OCC
-#define SEAMD_OCC 3
-#endif
 template <int LOGN, int MODE>
-__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kModeAsym ? 2 : SEAMD_OCC) : 1)) void k_encode_encrypt(DevParams P, DevTables T,
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kModeAsym ? 2 : 3) : 1)) void k_encode_encrypt(DevParams P, DevTables T,
                                                                           EncArgs A)
 {
     using G            = XformGeom<LOGN>;
@@ -198,24 +191,6 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
     {
         if (!A.c0) return;  // plain ckks_encode_base: only the int64 plaintext was requested
     }
-#ifdef SEAMD_MHI_LDS
-    // low words stay in registers, high words go to the LDS behind the NTT planes (the IFFT plane is
-    // free now: encode_plaintext ended with a barrier); each thread reads back only its own words
-    constexpr int TH       = G::THREADS;
-    constexpr int HI_PLANES = (MODE == kModeAsym && ASYM3) ? 3 : 1;
-    uint32_t *hi_lds       = lds32 + HI_PLANES * G::SLOTS + t;
-    uint32_t mlo[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) mlo[e] = (uint32_t)m[e];
-    if (!small)
-    {
-#pragma unroll
-        for (int e = 0; e < 16; e++) hi_lds[e * TH] = (uint32_t)((uint64_t)m[e] >> 32);
-    }
-#define SEAMD_REDUCE16(x) reduce_signed16_split(mlo, hi_lds, TH, x, q, crh, crl, small)
-#else
-#define SEAMD_REDUCE16(x) reduce_signed16(m, x, q, crh, crl, small)
-#endif
     for (int j = 0; j < np; j++)
     {
         const uint32_t q = P.q[j], two_q = q << 1;
@@ -238,7 +213,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 int32_t e1    = A.err[b * 2 * N + N + (e << CTOP) + t];
                 y[e]          = (e1 < 0 ? q : 0u) + (uint32_t)e1;
             }
-            SEAMD_REDUCE16(x);
+            reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
             {
                 // c1 = pk1 . u_hat + NTT(e1)   (:251)
@@ -299,7 +274,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 store16(A.c1 + off, out);
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
-            SEAMD_REDUCE16(x);
+            reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -319,7 +294,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         else
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
-            SEAMD_REDUCE16(x);
+            reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -635,12 +610,7 @@ static hipError_t launch_enc(const DevParams &P, const DevTables &T, const EncAr
     using G        = XformGeom<LOGN>;
     size_t shmem   = (size_t)G::SLOTS * sizeof(double);
     // public-key kernel, n <= 4096: three u32 planes for the three-way NTT
-    size_t shmem_asym = LOGN <= 12 ? std::max(shmem, (size_t)3 * G::SLOTS * sizeof(uint32_t)) : shmem;
-#ifdef SEAMD_MHI_LDS
-    // + n high words behind the NTT plane(s)
-    shmem      = std::max(shmem, (size_t)(G::SLOTS + G::N) * sizeof(uint32_t));
-    shmem_asym = std::max(shmem_asym, (size_t)((LOGN <= 12 ? 3 : 1) * G::SLOTS + G::N) * sizeof(uint32_t));
-#endif
+    const size_t shmem_asym = LOGN <= 12 ? std::max(shmem, (size_t)3 * G::SLOTS * sizeof(uint32_t)) : shmem;
     dim3 grid((unsigned)B), block(G::THREADS);
     switch (mode)
     {

@@ -90,36 +90,6 @@ __device__ __forceinline__ void reduce_signed16(const int64_t (&m)[16], uint32_t
     }
 }
 
-// The same with the plaintext split: low words in registers, high words parked in LDS (read back only
-// on the general path -- a wave whose magnitudes all fit 31 bits never touches them).  hi[e * stride]
-// is this thread's high word of coefficient slot e.
-__device__ __forceinline__ void reduce_signed16_split(const uint32_t (&mlo)[16], const uint32_t *hi,
-                                                      int stride, uint32_t (&x)[16], uint32_t q,
-                                                      uint32_t cr_hi, uint32_t cr_lo, bool small)
-{
-    if (small)
-    {
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-        {
-            int32_t v    = (int32_t)mlo[e];
-            bool neg     = v < 0;
-            uint32_t mag = neg ? 0u - (uint32_t)v : (uint32_t)v;
-            uint32_t r   = barrett32(mag, q, cr_hi);
-            x[e]         = neg ? q - r : r;
-        }
-    }
-    else
-    {
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-        {
-            const int64_t v = (int64_t)(((uint64_t)hi[e * stride] << 32) | (uint64_t)mlo[e]);
-            x[e]            = reduce_signed(v, q, cr_hi, cr_lo);
-        }
-    }
-}
-
 // Gentleman-Sande butterfly of the inverse NTT, inputs/outputs in [0,2q):
 // (U, V) -> (U + V, (U - V) * w)   (intt.c:188-195)
 __device__ __forceinline__ void gs_butterfly(uint32_t &x, uint32_t &y, uint32_t w, uint32_t wp,

@@ -258,8 +258,8 @@ __device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__r
     using G              = XformGeom<LOGN>;
     const uint32_t two_q = q << 1;
     constexpr int C0     = LOGN - 4;
+    constexpr int C1     = G::ntt_c(1);  // LOGN - 8
     ntt_pass<LOGN, C0, 0, 4>(x, RW, q, two_q, t);
-    constexpr int C1 = G::ntt_c(1);  // LOGN - 8
     redeal<C0, C1>(x, lds, t);
     ntt_pass<LOGN, C1, 0, 4>(x, RW, q, two_q, t);
     if constexpr (LOGN <= 12)
