@@ -318,6 +318,10 @@ int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags);
 /* pipeline shape of the symmetric path (A/B experiments): overlap = use the auxiliary stream,
  * split = 0 fused kernel, 1 per-prime software pipeline, 2 choose per call (default 1, 2). */
 int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split);
+/* pipeline shape of the public-key path (A/B experiments): chunks the batch is cut into so that the CBD
+ * sampler of chunk k+1 runs beside the fused kernel of chunk k (default 1 = serial, or
+ * $SE_AMD_ASYM_CHUNKS; batches below 4096 ciphertexts per chunk always run serially). */
+int se_amd_set_asym_chunks(se_amd_ctx *ctx, size_t chunks);
 const char *se_amd_last_error(void);
 const char *se_amd_version(void);
 

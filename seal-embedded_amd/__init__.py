@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_pack_ternary_host", "se_amd_word_ops_device", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
     "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
-    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_set_asym_chunks", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -120,6 +120,7 @@ def lib():
     L.se_amd_reserve.argtypes = [vp, sz]
     L.se_amd_set_debug_flags.argtypes = [vp, u32]
     L.se_amd_set_pipeline.argtypes = [vp, i32, i32]
+    L.se_amd_set_asym_chunks.argtypes = [vp, sz]
     _lib = L
     return L
 
@@ -388,6 +389,9 @@ class Context:
 
     def set_pipeline(self, overlap=True, split=True):
         _check(self.L.se_amd_set_pipeline(self.h, int(overlap), int(split)), "se_amd_set_pipeline")
+
+    def set_asym_chunks(self, chunks):
+        _check(self.L.se_amd_set_asym_chunks(self.h, chunks), "se_amd_set_asym_chunks")
 
     def set_debug_flags(self, flags):
         _check(self.L.se_amd_set_debug_flags(self.h, flags), "se_amd_set_debug_flags")

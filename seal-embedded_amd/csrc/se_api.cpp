@@ -402,6 +402,13 @@ int se_amd_set_pipeline(se_amd_ctx *ctx, int overlap, int split)
     return SE_SUCCESS;
 }
 
+int se_amd_set_asym_chunks(se_amd_ctx *ctx, size_t chunks)
+{
+    if (!ctx) return SE_ERR_INVALD_ARGUMENT;
+    ctx->c.asym_chunks = chunks ? chunks : 1;
+    return SE_SUCCESS;
+}
+
 int se_amd_set_speculation_capacity(se_amd_ctx *ctx, uint32_t cap)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;

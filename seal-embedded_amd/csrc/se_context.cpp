@@ -771,16 +771,23 @@ int Context::encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n;
 
-    // Per chunk: u first (its redraws decide where the CBD counters start, ckks_asym.c:188-201),
-    // then e0 (blocks 0..n/16-1) and e1 (blocks n/16..2n/16-1) contiguous per ciphertext, then the
-    // fused kernel.  The loop can cut the batch into chunks and run the samplers of chunk i+1 on
-    // the auxiliary stream beside the fused kernel of chunk i; measured at n=4096, B=65536 this is
-    // SLOWER (14.1 vs 12.2 ms per step): the ternary sampler is a per-ciphertext chain whose
-    // duration does not shrink with the chunk, and the fused kernel slows down when it shares the
-    // VALU.  One chunk is therefore the default.
-    const size_t nchunks = 1;
-    const size_t np      = hp.nprimes;
-    hipStream_t ax       = nchunks > 1 ? aux_stream : st;
+    // u first for the whole batch (its redraws decide where each ciphertext's CBD counters start,
+    // ckks_asym.c:188-201): the ternary sampler is a per-ciphertext chain, so its duration does not
+    // shrink with a chunk and it is launched once.  Then the batch is cut into chunks: the CBD sampler
+    // of chunk k+1 (e0 | e1 contiguous per ciphertext; VALU-throughput-bound) runs on the auxiliary
+    // stream beside the fused kernel of chunk k (latency-bound at 2 waves per SIMD), which leaves the
+    // CBD sampler's time mostly hidden.
+    //   S : ternary(all) ──fork──────► (wait C_0) E_0 ► (wait C_1) E_1 ► ...
+    //   A :                 └► C_0 ► C_1 ► C_2 ► ...
+    const size_t np = hp.nprimes;
+    size_t nchunks  = overlap ? asym_chunks : 1;
+    if (nchunks > (size_t)kMaxPrimes) nchunks = kMaxPrimes;   // one join event per chunk
+    if (nchunks < 1 || B < 4096 * nchunks) nchunks = 1;        // small batches: one chunk
+    TernaryArgs ta{d_seeds, d_ucodes, d_ctr, n, (uint32_t)B, nullptr, (uint32_t)num_cus};
+    stage_begin(2, st);
+    SEAMD_HIP(launch_sample_ternary(ta, st));
+    stage_end(st);
+    hipStream_t ax = nchunks > 1 ? aux_stream : st;
     if (nchunks > 1)
     {
         SEAMD_HIP(hipEventRecord(ev_fork, st));
@@ -790,19 +797,17 @@ int Context::encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d
     {
         const size_t lo = B * c / nchunks, hi = B * (c + 1) / nchunks, cb = hi - lo;
         if (cb == 0) continue;
-        TernaryArgs ta{d_seeds + lo * 64, d_ucodes + lo * n, d_ctr + lo, n, (uint32_t)cb, nullptr, (uint32_t)num_cus};
-        stage_begin(2, ax);
-        SEAMD_HIP(launch_sample_ternary(ta, ax));
-        stage_end(ax);
         CbdArgs ca{d_seeds + lo * 64, d_ctr + lo, d_err + lo * 2 * n, 2 * (n / 16), (uint32_t)cb};
         stage_begin(0, ax);
         SEAMD_HIP(launch_sample_cbd(ca, ax));
         stage_end(ax);
-        if (nchunks > 1)
-        {
-            SEAMD_HIP(hipEventRecord(ev_prime[c], ax));
-            SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[c], 0));
-        }
+        if (nchunks > 1) SEAMD_HIP(hipEventRecord(ev_prime[c], ax));
+    }
+    for (size_t c = 0; c < nchunks; c++)
+    {
+        const size_t lo = B * c / nchunks, hi = B * (c + 1) / nchunks, cb = hi - lo;
+        if (cb == 0) continue;
+        if (nchunks > 1) SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[c], 0));
         EncArgs ea{d_values + lo * (n / 2),
                    d_err + lo * 2 * n,
                    d_ucodes + lo * n,

@@ -1035,12 +1035,15 @@ def test_c_caller_of_reference_api_reproduces_reference_digest(env, golden, tmp_
     assert kv["fnv1a64"] == golden["digests"]["shapes"][f"{n}x{npr}"][f"api_fnv1a64_{mode}"]
 
 
-@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0"])
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0", "visible:0,0"])
 def test_c_caller_of_batch_entry(env, tmp_path, devices):
     """examples/batch_encrypt.c: se_encrypt_batch from C with malloc'ed (pageable) buffers; the
     records equal the oracle's per-ciphertext results in the reference's callback order.  With
     SE_AMD_DEVICES the batch is sharded over several contexts in one process (one host thread per
-    device; the same device listed repeatedly here, a single-GPU box, still exercises the split)."""
+    device; the same device listed repeatedly here, a single-GPU box, still exercises the split; 7
+    ciphertexts over 2 or 3 devices = unequal shards).  SE_AMD_DEVICES holds HIP ordinals, i.e. positions
+    in the process's visible-device list: under HIP_VISIBLE_DEVICES they are remapped like every HIP
+    index ("visible:" case), and an ordinal outside that list is refused at se_setup."""
     import subprocess
     from oracle import pyoracle
     from oracle.pyoracle import Oracle
@@ -1048,6 +1051,12 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
     exe = _build_example("batch_encrypt", tmp_path)
     data = _key_dir(env, tmp_path, n, npr, False)
     e = dict(os.environ, SE_AMD_DATA_PATH=str(data))
+    if devices and devices.startswith("visible:"):
+        e["HIP_VISIBLE_DEVICES"] = "0"
+        devices = devices.split(":", 1)[1]
+        bad = subprocess.run([str(exe), str(n), str(npr), str(B)], env=dict(e, SE_AMD_DEVICES="0,1"),
+                             capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and "device index out of range" in bad.stderr
     if devices:
         e["SE_AMD_DEVICES"] = devices
     out = subprocess.run([str(exe), str(n), str(npr), str(B)], env=e, check=True, capture_output=True,
@@ -1205,4 +1214,84 @@ def test_gen_keys_batch(env, golden, shape):
     ctx.decrypt_decode(c0, c1, 0, None, None, dvals)
     torch.cuda.synchronize()
     assert float((dvals.cpu() - torch.from_numpy(vals)).abs().max()) < 0.1
+    ctx.close()
+
+
+# --------------------------------------------------------------------------- one context, many callers
+def test_calls_from_two_streams_and_two_threads_are_ordered(env):
+    """A context has ONE set of scratch (error polynomial, counters, reject lists, auxiliary streams).
+    Calls issued back to back on DIFFERENT streams, and from different host threads, must still each
+    produce their own ciphertexts: the library orders successive calls on the scratch (event chain +
+    mutex, se_context.cpp begin_call / end_call).  Without that ordering the second call overwrites the
+    error polynomial the first one's fused kernel has yet to read."""
+    import threading
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 3000
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    jobs = []
+    for k in range(4):
+        vals = V.bench_values(B, n, first=10000 * k)
+        ss, sd = V.bench_seeds(B, first=10000 * k)
+        jobs.append(dict(vals=vals, ss=ss, sd=sd, dv=dev_t(env, vals), dss=dev_t(env, ss), dsd=dev_t(env, sd),
+                         c0=torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"]),
+                         c1=torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"]),
+                         stream=torch.cuda.Stream(), asym=(k == 3)))
+    torch.cuda.synchronize()
+
+    def issue(j):
+        with torch.cuda.stream(j["stream"]):
+            if j["asym"]:
+                ctx.encrypt_asym(j["dv"], j["dsd"], j["c0"], j["c1"])
+            else:
+                ctx.encrypt_sym(j["dv"], j["dss"], j["dsd"], j["c0"], j["c1"])
+
+    issue(jobs[0])                      # two streams, one thread, no synchronisation in between
+    issue(jobs[1])
+    th = [threading.Thread(target=issue, args=(jobs[k],)) for k in (2, 3)]   # two more from other threads
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    for k, j in enumerate(jobs):
+        for b in (0, 1, 63, 64, B // 2, B - 1):
+            r = (o.encrypt_asym(j["vals"][b], j["sd"][b].tobytes(), pk0, pk1) if j["asym"] else
+                 o.encrypt_sym(j["vals"][b], j["ss"][b].tobytes(), j["sd"][b].tobytes(), sk))
+            assert (host_u32(j["c0"][b]) == r["c0"]).all() and (host_u32(j["c1"][b]) == r["c1"]).all(), (k, b)
+    ctx.close()
+
+
+def test_asym_chunked_pipeline_is_bit_identical(env):
+    """The public-key path cut into chunks (CBD sampler of chunk k+1 beside the fused kernel of chunk
+    k on the auxiliary stream) gives the same bytes as the serial launch chain, for even and ragged
+    chunk boundaries."""
+    torch = env["torch"]
+    n, npr, B = 4096, 3, 3 * 4096 + 77
+    ctx = env["pkg"].Context(n, npr)
+    from oracle.pyoracle import Oracle
+    o = Oracle(n, npr)
+    sk = V.secret_key(n)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    vals, (_, sd) = V.bench_values(B, n), V.bench_seeds(B)
+    dv, dsd = dev_t(env, vals), dev_t(env, sd)
+    outs = []
+    for chunks in (1, 2, 3):
+        ctx.set_asym_chunks(chunks)
+        c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+        c1 = torch.zeros_like(c0)
+        ctx.encrypt_asym(dv, dsd, c0, c1)
+        torch.cuda.synchronize()
+        outs.append((c0, c1))
+    for c0, c1 in outs[1:]:
+        assert bool((c0 == outs[0][0]).all()) and bool((c1 == outs[0][1]).all())
+    for b in (0, 4095, 4096, B - 1):
+        r = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+        assert (host_u32(outs[0][0][b]) == r["c0"]).all() and (host_u32(outs[0][1][b]) == r["c1"]).all()
     ctx.close()
