@@ -55,6 +55,15 @@ DESCR = {
 }
 KERNEL_NAMES = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform", "ternary": "k_sample_ternary",
                 "encode_encrypt": "k_encode_encrypt", "encode_rns": "k_encode_rns", "ntt_fuse": "k_ntt_fuse"}
+# kernels a stage timer may cover when a stage is more than one kernel (none today)
+STAGE_KERNELS = {}
+
+
+def stage_profile(prof, stage, field):
+    """Sum of `field` over the kernels of a stage present in a profile dict, or None when none is."""
+    names = STAGE_KERNELS.get(stage, (KERNEL_NAMES[stage],))
+    vals = [prof[k][field] for k in names if k in prof]
+    return sum(vals) if vals else None
 
 
 def bytes_per_unit(mode, n, npr):
@@ -306,6 +315,8 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
             dist.barrier()
         be.sync()
 
+    if os.environ.get("SE_BENCH_DEBUG_FLAGS"):          # A/B of pipeline shapes (tools/c4_ab.sh)
+        ctx.set_debug_flags(int(os.environ["SE_BENCH_DEBUG_FLAGS"]))
     ctx.reserve(B)  # scratch allocation is not a step
     for _ in range(warmup):
         step()
@@ -344,11 +355,10 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
             continue
         kms = ms / prof_steps
         alg = kbytes.get(s, 0) * B
-        ent = pmc.get(KERNEL_NAMES[s])
         kernels.append({"kernel": KERNEL_NAMES[s], "ms_per_step": kms, "launches_per_step": cnt / prof_steps,
                         "algorithmic_bytes": alg, "achieved": alg / (kms * 1e-3) / 1e9,
                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": ent["hbm_bytes_per_step"] if ent else None})
+                        "traffic": stage_profile(pmc, s, "hbm_bytes_per_step")})
     # The dominant kernel is the longest one ON THE MAIN STREAM (the critical path).  The CBD sampler of
     # the symmetric pipeline runs on the auxiliary stream beside the uniform sampler: its elapsed time is
     # stretched by the co-runner and says nothing about the step.
@@ -357,11 +367,12 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
     dom = max(main, key=lambda k: k["ms_per_step"]) if main else None
     achieved = bpu * B / (ms_per_step * 1e-3) / 1e9
     traffic = None
-    if pmc and all(KERNEL_NAMES[s] in pmc for s, (ms, cnt) in stages.items() if cnt):
-        traffic = sum(pmc[KERNEL_NAMES[s]]["hbm_bytes_per_step"] for s, (ms, cnt) in stages.items() if cnt)
+    used = [s for s, (ms, cnt) in stages.items() if cnt]
+    if pmc and all(stage_profile(pmc, s, "hbm_bytes_per_step") is not None for s in used):
+        traffic = sum(stage_profile(pmc, s, "hbm_bytes_per_step") for s in used)
     valu = None
-    if sq and all(KERNEL_NAMES[s] in sq for s, (ms, cnt) in stages.items() if cnt):
-        insts = sum(sq[KERNEL_NAMES[s]]["valu_wave_insts_per_step"] for s, (ms, cnt) in stages.items() if cnt)
+    if sq and all(stage_profile(sq, s, "valu_wave_insts_per_step") is not None for s in used):
+        insts = sum(stage_profile(sq, s, "valu_wave_insts_per_step") for s in used)
         simds = 4 * be.num_cus
         floor_ms = insts * 4.0 / simds / VALU_CLOCK_HZ * 1e3
         valu = {"bound": "valu", "wave_insts_per_step": insts, "simds": simds, "clock_hz": VALU_CLOCK_HZ,
@@ -378,6 +389,10 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
     if gather_plan:
         from seal_embedded_amd.sharding import gather_records
         sizes = [B] * world
+        # untimed warm-up of the point-to-point connections (RCCL builds them on first use)
+        gather_records(c0[:1], dist, dst=0, out=c0_all[:world] if rank == 0 else None, sizes=[1] * world)
+        if rank == 0:
+            step()                                  # restore the root's record 0..world-1 region
         fence()
         g0 = time.perf_counter()
         gather_records(c0, dist, dst=0, out=c0_all, sizes=sizes)

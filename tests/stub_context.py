@@ -51,6 +51,9 @@ class Context:
             status.fill_(1 if ok else 0)
         self.calls += 1
 
+    def set_debug_flags(self, flags):
+        pass
+
     def set_profiling(self, on=True):
         pass
 

@@ -1295,3 +1295,4 @@ def test_asym_chunked_pipeline_is_bit_identical(env):
         r = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
         assert (host_u32(outs[0][0][b]) == r["c0"]).all() and (host_u32(outs[0][1][b]) == r["c1"]).all()
     ctx.close()
+
