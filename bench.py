@@ -424,7 +424,8 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
                   else "CKKS plaintexts/s (batched encode + RNS NTT)",
         "value": world * B * steps / elapsed, "unit": unit, "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic" if not be.stub else "stub-oracle (test harness of the rank logic, NOT a measurement)",
         "config": {"workload": DESCR[name] + f", batch={B} per GPU", "n": n, "nprimes": npr, "mode": mode,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}",
                    "bytes_per_unit": bpu},

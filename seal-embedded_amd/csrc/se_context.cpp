@@ -638,6 +638,7 @@ bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
         plan.offset[j]   = (uint32_t)off;
         off += (uint64_t)B * plan.count[j];
         if (off > (uint64_t)small_limit) return false;  // beyond this it stops paying
+        if (off * hp.n * sizeof(uint32_t) > small_bytes) return false;  // scratch rows bounded in bytes
     }
     plan.total = (uint32_t)off;
     return true;

@@ -66,6 +66,8 @@ struct Context
     uint32_t *d_sp_fail   = nullptr;  // [sp_fail_cap] 0 = chain resolved, j = window of prime j missed
     size_t sp_cap = 0, sp_fail_cap = 0;
     uint32_t small_limit = getenv("SE_AMD_SMALL_LIMIT") ? (uint32_t)atoi(getenv("SE_AMD_SMALL_LIMIT")) : 65536;  // virtual ciphertexts a small call may fan out to
+    // ... and the bytes their output rows may take (one n-word row per virtual ciphertext)
+    size_t small_bytes = getenv("SE_AMD_SMALL_BYTES") ? (size_t)atoll(getenv("SE_AMD_SMALL_BYTES")) : ((size_t)1 << 30);
     hipStream_t sp_streams[kMaxPrimes] = {};
     size_t scratch_cap = 0;   // ciphertexts d_err / d_ucodes / d_ctr hold
     size_t rows_cap    = 0;   // rows of d_rej / d_spec (>= scratch_cap: virtual ciphertexts need only these)
