@@ -73,6 +73,8 @@ void reduce_set_pte(const Parms *parms, const int64_t *conj_vals_int, ZZ *out);
 void reduce_add_pte(const Parms *parms, const int64_t *conj_vals_int, ZZ *out);
 void reduce_set_e_small(const Parms *parms, const int8_t *e, ZZ *out);
 void reduce_add_e_small(const Parms *parms, const int8_t *e, ZZ *out);
+/* the banner the reference prints before carving a pool (ckks_common.c:336-380) */
+void print_ckks_mempool_size(size_t n, bool sym);
 
 /* ---- fft.h:70-109 -------------------------------------------------------------------------- */
 /* roots[i] = e^{+-2 pi i bitrev(i) / 2n} from the host libm (fft.c:47-67); the transforms below
@@ -95,6 +97,16 @@ void intt_inpl(const Parms *parms, const ZZ *intt_roots, ZZ *vec); /* intt.c:144
 /* ---- sample.h:139-348 (the samplers of the default configuration) --------------------------- */
 void sample_poly_uniform(const Parms *parms, SE_PRNG *prng, ZZ *poly);                  /* sample.c:39-57 */
 void expand_poly_ternary(const ZZ *src, const Parms *parms, ZZ *dest);                  /* sample.c:113-129 */
+void expand_poly_ternary_inpl(ZZ *poly, const Parms *parms);                            /* sample.c:131-136 */
+/* accessors of the 2-bit packed form (sample.c:61-111): host-side format helpers */
+void set_small_poly_idx(size_t idx, uint8_t val_in, ZZ *poly);
+uint8_t get_small_poly_idx(const ZZ *poly, size_t idx);
+ZZ get_small_poly_idx_expanded(const ZZ *poly, size_t idx, ZZ q);
+/* expanded ternary polynomial of the previous prime -> current prime (sample.c:138-153) */
+void convert_poly_ternary(const ZZ *src, const Parms *parms, ZZ *dest);
+void convert_poly_ternary_inpl(ZZ *poly, const Parms *parms);
+/* expanded (non-small) uniform ternary polynomial mod the current prime (sample.c:155-188) */
+void sample_poly_ternary(const Parms *parms, SE_PRNG *prng, ZZ *poly);
 void sample_small_poly_ternary_prng_96(PolySizeType n, SE_PRNG *prng, ZZ *poly);        /* sample.c:218-242 */
 void sample_poly_cbd_generic_prng_16(PolySizeType n, SE_PRNG *prng, int8_t *poly);      /* sample.c:311-321 */
 void sample_add_poly_cbd_generic_inpl_prng_16(int64_t *poly, PolySizeType n, SE_PRNG *prng); /* :347-356 */

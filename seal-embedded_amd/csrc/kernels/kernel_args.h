@@ -133,6 +133,8 @@ hipError_t launch_word_ops(const DevParams &, int j, int op, const uint64_t *a, 
                            const uint64_t *c, uint32_t *out, size_t count, hipStream_t);
 hipError_t launch_add_small(int64_t *m, const int8_t *e, size_t total, hipStream_t);
 hipError_t launch_pack_ternary(const int8_t *codes, uint8_t *packed, size_t total_bytes, hipStream_t);
+hipError_t launch_ternary_words(const uint32_t *in, uint32_t *out, uint32_t *nrej, uint32_t q, uint32_t n, int op,
+                                hipStream_t);
 hipError_t launch_expand_ternary(const uint8_t *packed, uint32_t *out, uint32_t q, uint32_t n, hipStream_t);
 hipError_t launch_lower_sym_prime(const DevParams &, const DevTables &, const LowerSymArgs &, size_t count,
                                   hipStream_t);

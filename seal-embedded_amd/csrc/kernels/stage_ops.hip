@@ -217,6 +217,30 @@ hipError_t launch_pack_ternary(const int8_t *codes, uint8_t *packed, size_t tota
     return hipGetLastError();
 }
 
+// convert_poly_ternary (sample.c:138-148): entries > 1 (i.e. q_prev - 1) become q - 1
+// sample_poly_ternary's word mapping (sample.c:176-186): w -> (w mod 3) + (w == 0 ? q : 0) - 1 in 32-bit
+// arithmetic, literally as the reference computes it; words >= 0xFFFFFFFE are flagged for a redraw
+__global__ void k_ternary_words(const uint32_t *in, uint32_t *out, uint32_t *nrej, uint32_t q, uint32_t n, int op)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t w = in[k];
+    if (op == 0)
+        out[k] = w > 1 ? q - 1 : w;
+    else
+    {
+        if (w >= 0xFFFFFFFEu) atomicAdd(nrej, 1u);
+        out[k] = (w % 3u) + (w == 0 ? q : 0u) - 1u;
+    }
+}
+
+hipError_t launch_ternary_words(const uint32_t *in, uint32_t *out, uint32_t *nrej, uint32_t q, uint32_t n, int op,
+                                hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ternary_words, dim3((n + 255) / 256), dim3(256), 0, st, in, out, nrej, q, n, op);
+    return hipGetLastError();
+}
+
 __global__ void k_expand_ternary(const uint8_t *packed, uint32_t *out, uint32_t q, uint32_t n)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -392,6 +392,28 @@ static void reduce_generic(const Parms *parms, const int64_t *pte, const int8_t 
     down(out, L.u32[0], 4 * n);
 }
 
+void print_ckks_mempool_size(size_t n, bool sym)
+{
+    // same text as ckks_common.c:336-380 for the default configuration (values buffer inside the pool)
+    size_t pool = sym ? ckks_get_mempool_size_sym(n) : ckks_get_mempool_size_asym(n);
+    const char *txt[2] = {"\nTotal memory requirement (incl. values buffer)  :",
+                          "\nTotal memory requirement (without values buffer):"};
+    for (int i = 0; i < 2; i++)
+    {
+        const size_t bytes = pool * sizeof(ZZ);
+        if (bytes / 1024)
+            printf("%s %zu KB\n", txt[i], bytes / 1024);
+        else
+            printf("%s %zu bytes\n", txt[i], bytes);
+        printf("\t( i.e. [(degree = %zu) * (sizeof(ZZ) = %zu bytes) = ", n, sizeof(ZZ));
+        if (n * sizeof(ZZ) / 1024)
+            printf("%zu KB] * %0.4f )\n\n", n * sizeof(ZZ) / 1024, pool / (double)n);
+        else
+            printf("%zu bytes] * %0.4f )\n\n", n * sizeof(ZZ), pool / (double)n);
+        pool -= n / 2;
+    }
+}
+
 void reduce_set_pte(const Parms *parms, const int64_t *conj_vals_int, ZZ *out)
 {
     reduce_generic(parms, conj_vals_int, nullptr, out, false);
@@ -528,6 +550,75 @@ void expand_poly_ternary(const ZZ *src, const Parms *parms, ZZ *dest)
     up(L.packed, src, L.n / 4);
     LOWER_HIP(seamd::launch_expand_ternary(L.packed, L.u32[0], parms->curr_modulus->value, (uint32_t)L.n, nullptr));
     down(dest, L.u32[0], 4 * L.n);
+}
+
+void expand_poly_ternary_inpl(ZZ *poly, const Parms *parms) { expand_poly_ternary(poly, parms, poly); }
+
+// sample.c:61-111: accessors of the packed form (data layout, not arithmetic)
+void set_small_poly_idx(size_t idx, uint8_t val_in, ZZ *poly)
+{
+    uint8_t *b     = reinterpret_cast<uint8_t *>(poly);
+    const int sh   = 6 - 2 * (int)(idx % 4);
+    b[idx / 4]     = (uint8_t)((b[idx / 4] & ~(0x3 << sh)) | ((val_in & 0x3) << sh));
+}
+
+uint8_t get_small_poly_idx(const ZZ *poly, size_t idx)
+{
+    return (reinterpret_cast<const uint8_t *>(poly)[idx / 4] >> (6 - 2 * (idx % 4))) & 0x3;
+}
+
+ZZ get_small_poly_idx_expanded(const ZZ *poly, size_t idx, ZZ q)
+{
+    const ZZ v = get_small_poly_idx(poly, idx);
+    return v + (v == 0 ? q : 0) - 1;
+}
+
+void convert_poly_ternary(const ZZ *src, const Parms *parms, ZZ *dest)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Lower &L = lower_for(parms);
+    LOWER_HIP(hipSetDevice(L.c().device));
+    up(L.u32[0], src, 4 * L.n);
+    LOWER_HIP(seamd::launch_ternary_words(L.u32[0], L.u32[1], nullptr, parms->curr_modulus->value, (uint32_t)L.n, 0,
+                                          nullptr));
+    down(dest, L.u32[1], 4 * L.n);
+}
+
+void convert_poly_ternary_inpl(ZZ *poly, const Parms *parms) { convert_poly_ternary(poly, parms, poly); }
+
+void sample_poly_ternary(const Parms *parms, SE_PRNG *prng, ZZ *poly)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Lower &L       = lower_for(parms);
+    const size_t n = L.n;
+    const ZZ q     = parms->curr_modulus->value;
+    LOWER_HIP(hipSetDevice(L.c().device));
+    // one 4n-byte block, then one 4-byte block per rejected word (>= 0xFFFFFFFE: 2^-31 per word)
+    put_prng(L, prng);
+    const uint32_t zero = 0;
+    up(L.fail, &zero, 4);
+    LOWER_HIP(seamd::launch_prng_blocks(L.seed, L.ctr, (uint8_t *)L.u32[0], (uint32_t)(4 * n), 1, nullptr));
+    LOWER_HIP(seamd::launch_ternary_words(L.u32[0], L.u32[1], L.fail, q, (uint32_t)n, 1, nullptr));
+    uint32_t nrej = 0;
+    down(&nrej, L.fail, 4);
+    down(poly, L.u32[1], 4 * n);
+    uint64_t before = prng->counter;
+    prng->counter++;
+    after_draws(prng, before);
+    if (nrej)
+    {
+        std::vector<uint32_t> words(n);
+        down(words.data(), L.u32[0], 4 * n);
+        for (size_t i = 0; i < n; i++)
+        {
+            uint32_t w = words[i];
+            if (w < 0xFFFFFFFEu) continue;
+            while (w >= 0xFFFFFFFEu) prng_fill_buffer(4, prng, &w);
+            up(L.u32[2], &w, 4);
+            LOWER_HIP(seamd::launch_ternary_words(L.u32[2], L.u32[3], L.fail, q, 1, 1, nullptr));
+            down(&poly[i], L.u32[3], 4);
+        }
+    }
 }
 
 void sample_small_poly_ternary_prng_96(PolySizeType n, SE_PRNG *prng, ZZ *poly)

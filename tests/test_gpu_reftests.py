@@ -1,0 +1,63 @@
+"""GPU tests (-m gpu): the REFERENCE'S OWN test functions (device/test/ckks_tests_sym.c, ckks_tests_asym.c,
+ckks_tests_encode.c, ntt_tests.c, fft_tests.c, sample_tests.c, api_tests.c), compiled in the build
+container from where they lie with the reference's own headers and LINKED AGAINST
+libseal_embedded_amd.so instead of device/lib (`make -C oracle reftests` -> oracle/_ref/ref_tests_gpu, a
+built artefact that travels to the GPU box; the sources never enter the repo).  Their checks are the
+reference's se_assert()s -- decrypt + decode within 0.1 for the nine input patterns on every prime, NTT
+multiplication against the schoolbook product, FFT round trips, sampler statistics -- and abort the
+process when they fail.  This is the relink a SEAL-Embedded maintainer would do; skipped when the
+artefact was not built (no /root/reference at build time)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import vectors as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "ref_tests_gpu")
+pytestmark = pytest.mark.gpu
+
+CASES = [("fft", 1024, 1), ("fft", 4096, 1), ("fft", 16384, 1),
+         ("ntt", 1024, 1), ("ntt", 4096, 3),
+         ("encode", 1024, 1), ("encode", 4096, 1), ("encode", 16384, 1),
+         ("sym", 1024, 1), ("sym", 4096, 3), ("sym", 16384, 6), ("zero_sym", 4096, 3),
+         ("asym", 1024, 1), ("asym", 4096, 3), ("asym", 8192, 6), ("zero_asym", 4096, 3),
+         ("uniform", 4096, 1), ("ternary", 4096, 1), ("ternary_small", 4096, 1),
+         ("api_sym", 4096, 3), ("api_asym", 4096, 3)]
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/ref_tests_gpu not built (needs /root/reference at build time)")
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    d = tmp_path_factory.mktemp("reftests")
+    data = d / "adapter_output_data"
+    data.mkdir()
+    for n in (1024, 2048, 4096, 8192, 16384):
+        V.secret_key(n).tofile(data / f"sk_{n}.dat")
+    # public key files for the API test (se_setup_default: n = 4096, 3 primes), from the library's gen_pk
+    ctx = pkg.Context(4096, 3)
+    pk0, pk1 = ctx.gen_public_key(V.secret_key(4096), hashlib.shake_256(b"golden-pk").digest(64),
+                                  hashlib.shake_256(b"golden-ep").digest(64))
+    for j, q in enumerate(ctx.moduli()):
+        pk0[j].tofile(data / f"pk0_ntt_4096_{q}.dat")
+        pk1[j].tofile(data / f"pk1_ntt_4096_{q}.dat")
+    ctx.close()
+    return d
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}")
+def test_reference_test_function_passes_on_the_gpu_library(workdir, case):
+    name, n, npr = case
+    r = subprocess.run([EXE, name, str(n), str(npr)], cwd=workdir, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"rc={r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-1500:]}"
+    assert f"REF_TEST_DONE {name} {n} {npr}" in r.stderr
+    assert "Assertion" not in r.stderr and "Error!" not in r.stdout[-400:]
