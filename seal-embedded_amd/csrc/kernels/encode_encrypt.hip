@@ -121,9 +121,9 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
 
     // round to int64, overflow check (ckks_common.c:183-206).  The largest magnitude of the thread
     // serves both the overflow test and the wave-uniform "small" flag: when every coefficient of
-    // the wave stays below 2^31 - 64 (the normal case, |m| ~ scale * |value|; the margin covers the
-    // error term added later, |e| <= 21) the int64 conversion is one v_cvt_i32_f64 plus a sign
-    // extension, and the per-prime reduction can work on 32-bit magnitudes without re-checking.
+    // the wave stays below 2 q_min - 64 (< 2^31; the normal case, |m| ~ scale * |value|; the margin
+    // covers the error term added later, |e| <= 21) the int64 conversion is one v_cvt_i32_f64 plus a
+    // sign extension, and the per-prime "reduction" is the single add m + 2q (modarith.cuh).
     double amax = 0.0;
 #pragma unroll
     for (int e = 0; e < 16; e++)
@@ -132,7 +132,7 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
         amax  = fmax(amax, fabs(re[e]));
     }
     const int ok = !(amax > 9223372036854775808.0);
-    small        = __all(amax < 2147483584.0);
+    small        = __all(amax < P.small_bound);
     if (small)
     {
 #pragma unroll
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
     const int np   = P.nprimes;
 
     int64_t m[16];
-    bool small;  // wave-uniform: every |m + e| of this wave fits 31 bits
+    bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
     encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
 
     // thread t now owns points k = t + (n/16)*e
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             for (int e = 0; e < 16; e++)
             {
                 uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
-                uh[e]         = code + (code == 0 ? q : 0u) - 1u;
+                uh[e]         = code + q - 1u;            // q-1, q, q+1 == -1, 0, 1 (sample.c:98-111 mod q)
                 int32_t e1    = A.err[b * 2 * N + N + (e << CTOP) + t];
-                y[e]          = (e1 < 0 ? q : 0u) + (uint32_t)e1;
+                y[e]          = q + (uint32_t)e1;          // == reduce_set_e_small (ckks_common.c:259-265) mod q
             }
             reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             for (int e = 0; e < 16; e++)
             {
                 uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
-                uh[e]         = code + (code == 0 ? q : 0u) - 1u;
+                uh[e]         = code + q - 1u;
             }
             ntt_tiles<LOGN>(uh, RW, q, lds32, t);
             // c1 = pk1 . u_hat + NTT(e1)   (:251, :263-272)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             for (int e = 0; e < 16; e++)
             {
                 int32_t e1 = A.err[b * 2 * N + N + (e << CTOP) + t];
-                x[e]       = (e1 < 0 ? q : 0u) + (uint32_t)e1;
+                x[e]       = q + (uint32_t)e1;
             }
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
             {
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         else
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
-            reduce_signed16(m, x, q, crh, crl, small);
+            reduce_signed16<MODE != kModeSym>(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
+                                                                          // symmetric kernel keeps the exact form
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
     const int np   = P.nprimes;
 
     int64_t m[16];
-    bool small;  // wave-uniform: every |m + e| of this wave fits 31 bits
+    bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
     encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
     if constexpr (ADD_ERR)
     {

@@ -109,6 +109,11 @@ DevParams to_dev_params(const HostParams &hp)
         // sample.c:45-46: max_multiple = 0xFFFFFFFF - (0xFFFFFFFF mod q) - 1
         d.bound[j] = 0xFFFFFFFFu - (0xFFFFFFFFu % hp.q[j]) - 1u;
     }
+    {
+        uint32_t qmin = hp.q[0];
+        for (size_t j = 1; j < hp.nprimes; j++) qmin = hp.q[j] < qmin ? hp.q[j] : qmin;
+        d.small_bound = 2.0 * (double)qmin - 64.0;   // < 2^31 for every tabulated prime
+    }
     d.n_inv = hp.scale / (double)hp.n;
     d.scale = hp.scale;
     for (size_t j = 0; j < hp.nprimes; j++)

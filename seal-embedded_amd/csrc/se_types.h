@@ -24,6 +24,7 @@ struct DevParams
     uint32_t inv_n_sh[kMaxPrimes]; // floor(inv_n * 2^32 / q)
     double scale;                  // CKKS scale (decode divides by it)
     uint32_t num_cus;              // compute units of the device (launch geometry of the chain kernels)
+    double small_bound;            // 2 min_j q_j - 64: below it every |m + e| of a plaintext lies in (-2 q_j, 2 q_j)
 };
 
 // Device-resident read-only tables (pointers into one HBM slab owned by the context).

@@ -606,8 +606,9 @@ def test_encode_coefficient_of_exactly_2_pow_63(env):
 
 @pytest.mark.parametrize("n,npr", [(4096, 3), (1024, 1)])
 def test_magnitude_classes_through_every_path(env, n, npr):
-    """The encoder has a wave-uniform fast path for coefficients below 2^31 - 64 (one-instruction
-    int conversion, 32-bit reduction) and a general int64 path.  Plaintexts whose coefficients sit
+    """The encoder has a wave-uniform fast path for coefficients below 2 q_min - 64 (one-instruction
+    int conversion; m + 2q as the NTT's input representative instead of a signed reduction) and a general
+    int64 path.  Plaintexts whose coefficients sit
     well below, just around (2^31 -/+ a few) and far above that boundary go through encode-only,
     symmetric and public-key encryption and must match the oracle (values chosen per row, so
     different waves/workgroups take different paths in one launch)."""
@@ -617,7 +618,9 @@ def test_magnitude_classes_through_every_path(env, n, npr):
     scale = o.p.scale
     rng = np.random.default_rng(1234 + n)
     rows = []
-    for amp in (1e-3, 1.0, 30.0, 2.0 ** 31 / scale * 0.999, 2.0 ** 31 / scale * 1.001, 1e3, 1e6, 1e9):
+    two_q = 2.0 * min(o.q)          # the fast path needs every |m + e| < 2 q_min (single-add representative)
+    for amp in (1e-3, 1.0, 30.0, two_q / scale * 0.99, two_q / scale * 0.99999, two_q / scale * 1.00001,
+                two_q / scale * 1.01, 2.0 ** 31 / scale * 0.999, 2.0 ** 31 / scale * 1.001, 1e3, 1e6, 1e9):
         rows.append((rng.uniform(-1, 1, n // 2) * amp).astype(np.float32))
         one = np.zeros(n // 2, dtype=np.float32)
         one[int(rng.integers(0, n // 2))] = amp * n / 2       # a single large slot: flat coefficients ~ amp
@@ -642,7 +645,7 @@ def test_magnitude_classes_through_every_path(env, n, npr):
         assert bool(gs[b]) == ok, b
         if not ok:
             continue
-        kinds.add(bool(np.abs(m).max() < 2 ** 31 - 64))
+        kinds.add(bool(np.abs(m).max() < two_q - 64))
         assert (gp[b] == m).all(), b
         for j in range(npr):
             assert (g[b, j] == o.ntt(o.reduce_pte(m, j), j)).all(), (b, j)
