@@ -63,6 +63,57 @@ __device__ __forceinline__ void load16_pairs(uint32_t (&w)[16], uint32_t (&wp)[1
     }
 }
 
+// quad-layout (transform.cuh, tile_to_quads) accessors: every instruction of a wave covers 1 KiB contiguous
+__device__ __forceinline__ void load_quads(uint32_t (&v)[16], const uint32_t *poly, int t)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const uint4 w = *reinterpret_cast<const uint4 *>(poly + quad_index(t, i));
+        v[4 * i] = w.x, v[4 * i + 1] = w.y, v[4 * i + 2] = w.z, v[4 * i + 3] = w.w;
+    }
+}
+
+__device__ __forceinline__ void store_quads(uint32_t *poly, const uint32_t (&v)[16], int t)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        *reinterpret_cast<uint4 *>(poly + quad_index(t, i)) =
+            make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+// interleaved (value, shoup) pairs of one polynomial's table, quad layout
+__device__ __forceinline__ void load_quads_pairs(uint32_t (&w)[16], uint32_t (&wp)[16], const uint32_t *tab,
+                                                 int t)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(tab + 2 * (size_t)quad_index(t, i));
+        const uint4 a = p4[0], b = p4[1];
+        w[4 * i] = a.x, wp[4 * i] = a.y, w[4 * i + 1] = a.z, wp[4 * i + 1] = a.w;
+        w[4 * i + 2] = b.x, wp[4 * i + 2] = b.y, w[4 * i + 3] = b.z, wp[4 * i + 3] = b.w;
+    }
+}
+
+// epilogue accessors in whichever layout the kernel's outputs are in: quad layout after tile_to_quads,
+// else the thread's 16 consecutive coefficients
+template <bool QUADS>
+__device__ __forceinline__ void ld_poly(uint32_t (&v)[16], const uint32_t *poly, int t)
+{
+    if constexpr (QUADS) load_quads(v, poly, t); else load16(v, poly + 16 * t);
+}
+template <bool QUADS>
+__device__ __forceinline__ void st_poly(uint32_t *poly, const uint32_t (&v)[16], int t)
+{
+    if constexpr (QUADS) store_quads(poly, v, t); else store16(poly + 16 * t, v);
+}
+template <bool QUADS>
+__device__ __forceinline__ void ld_pairs(uint32_t (&w)[16], uint32_t (&wp)[16], const uint32_t *tab, int t)
+{
+    if constexpr (QUADS) load_quads_pairs(w, wp, tab, t); else load16_pairs(w, wp, tab, (size_t)16 * t);
+}
+
 // ------------------------------------------------------------------------------------------
 // Encode front end shared by the fused and the split kernels: values -> LDS -> gather through the
 // inverse index map -> inverse FFT -> round to int64 (+ overflow status).  On return thread t owns
@@ -191,12 +242,23 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
     {
         if (!A.c0) return;  // plain ckks_encode_base: only the int64 plaintext was requested
     }
+    // Outputs leave the kernel in quad layout (n <= 4096: the wave-local transpose region sits behind the
+    // NTT plane(s), so it needs no barrier against the next prime's exchanges)
+    // (the public-key kernel keeps the tile layout: three transposes per prime push it into spills and
+    // measure 0.5 % slower, gpurun_out/ab_quads2.log)
+    constexpr bool QUADS   = LOGN <= 12 && MODE != kModeAsym;
+    constexpr int QSTRIDE  = 28;
+    uint32_t *qlds         = lds32 + G::SLOTS;
+    auto to_quads = [&](uint32_t (&v)[16]) {
+        if constexpr (QUADS) tile_to_quads<QSTRIDE>(v, qlds, t);
+    };
     for (int j = 0; j < np; j++)
     {
         const uint32_t q = P.q[j], two_q = q << 1;
         const uint32_t crh = P.cr_hi[j], crl = P.cr_lo[j];
         const uint32_t *RW = T.ntt_rw + (size_t)2 * N * j;
-        const size_t off   = (b * np + j) * N + 16 * t;  // this thread's 16 output coefficients
+        const size_t pb    = (b * np + j) * N;            // this polynomial in the [ct][prime][coeff] slabs
+        const size_t kb    = (size_t)2 * N * j;           // this prime's rows of the (value, shoup) key tables
         uint32_t x[16];
 
         if constexpr (MODE == kModeAsym && ASYM3)
@@ -218,29 +280,29 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             {
                 // c1 = pk1 . u_hat + NTT(e1)   (:251)
                 uint32_t w[16], wp[16], out[16];
-                load16_pairs(w, wp, T.pk1, (size_t)j * N + 16 * t);
+                ld_pairs<false>(w, wp, T.pk1 + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     out[e]      = csub(pr + canon4(y[e], q, two_q), q);
                 }
-                store16(A.c1 + off, out);
+                st_poly<QUADS>(A.c1 + pb, out, t);
             }
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
-            if (A.ntt_pte) store16(A.ntt_pte + off, x);
+            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, t);
             {
                 // c0 = pk0 . u_hat + NTT(m + e0)   (:255)
                 uint32_t w[16], wp[16], out[16];
-                load16_pairs(w, wp, T.pk0, (size_t)j * N + 16 * t);
+                ld_pairs<false>(w, wp, T.pk0 + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     out[e]      = csub(pr + x[e], q);
                 }
-                store16(A.c0 + off, out);
+                st_poly<QUADS>(A.c0 + pb, out, t);
             }
         }
         else if constexpr (MODE == kModeAsym)
@@ -264,31 +326,31 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
             {
                 uint32_t w[16], wp[16], out[16];
-                load16_pairs(w, wp, T.pk1, (size_t)j * N + 16 * t);
+                ld_pairs<false>(w, wp, T.pk1 + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     out[e]      = csub(pr + canon4(x[e], q, two_q), q);
                 }
-                store16(A.c1 + off, out);
+                st_poly<false>(A.c1 + pb, out, t);
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
             reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
-            if (A.ntt_pte) store16(A.ntt_pte + off, x);
+            if (A.ntt_pte) st_poly<false>(A.ntt_pte + pb, x, t);
             {
                 uint32_t w[16], wp[16], out[16];
-                load16_pairs(w, wp, T.pk0, (size_t)j * N + 16 * t);
+                ld_pairs<false>(w, wp, T.pk0 + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     out[e]      = csub(pr + x[e], q);
                 }
-                store16(A.c0 + off, out);
+                st_poly<false>(A.c0 + pb, out, t);
             }
         }
         else
@@ -299,24 +361,25 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
-            if (A.ntt_pte) store16(A.ntt_pte + off, x);
+            to_quads(x);
+            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, t);
             if constexpr (MODE == kModeSym)
             {
                 // c0 = -(s_hat . a) + NTT(m+e)   (ckks_sym.c:273-300); a was written to c1
                 uint32_t a[16], w[16], wp[16], out[16];
-                load16(a, A.c1 + off);
-                load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+                ld_poly<QUADS>(a, A.c1 + pb, t);
+                ld_pairs<QUADS>(w, wp, T.s_hat + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
                     out[e]      = csub(x[e] + q - pr, q);
                 }
-                store16(A.c0 + off, out);
+                st_poly<QUADS>(A.c0 + pb, out, t);
             }
             else
             {
-                store16(A.c0 + off, x);
+                st_poly<QUADS>(A.c0 + pb, x, t);
             }
         }
     }
@@ -382,25 +445,29 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     const int np     = P.nprimes;
     const uint32_t q = P.q[j], two_q = q << 1;
     uint32_t *poly   = A.c0 + (b * np + j) * N;
-    const size_t off = (b * np + j) * N + 16 * t;
 
     uint32_t x[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = poly[(e << CTOP) + t];
     // issue the epilogue operands now; they land while the NTT runs.  At n = 16384 only `a` (HBM) is
     // prefetched; the L2-resident s_hat pairs are fetched after the NTT to stay within 96 VGPRs.
+    // All epilogue accesses are in quad layout (transform.cuh, tile_to_quads): 1 KiB contiguous per wave
+    // instruction instead of 16-byte pieces at a 64 / 128-byte lane stride.
     constexpr bool LATE_KEY = LOGN == 14;
     uint32_t a[16], w[16], wp[16];
     if constexpr (MODE == kModeSym)
     {
-        load16(a, A.c1 + off);
-        if constexpr (!LATE_KEY) load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+        load_quads(a, A.c1 + (b * np + j) * N, t);
+        if constexpr (!LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
     }
     ntt_tiles<LOGN>(x, T.ntt_rw + (size_t)2 * N * j, q, lds32, t);
-    if constexpr (MODE == kModeSym && LATE_KEY) load16_pairs(w, wp, T.s_hat, (size_t)j * N + 16 * t);
+    if constexpr (MODE == kModeSym && LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
-    if (A.ntt_pte) store16(A.ntt_pte + off, x);
+    // one prime per launch: the exchange plane is free after the NTT's last barrier, the wave-local
+    // transpose runs inside it (unpadded rows: the plane has no room for more at n = 16384 beside the chains)
+    tile_to_quads<16>(x, lds32, t);
+    if (A.ntt_pte) store_quads(A.ntt_pte + (b * np + j) * N, x, t);
     if constexpr (MODE == kModeSym)
     {
         uint32_t out[16];
@@ -410,11 +477,11 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
             uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
             out[e]      = csub(x[e] + q - pr, q);
         }
-        store16(poly + 16 * t, out);
+        store_quads(poly, out, t);
     }
     else
     {
-        store16(poly + 16 * t, x);
+        store_quads(poly, x, t);
     }
 }
 
@@ -454,7 +521,9 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_ntt_polys(DevParam
 }
 
 // Shoup companions for a table that is already in NTT form (public-key slabs): pairs[i] =
-// (v[i], floor(v[i] * 2^32 / q_j)).
+// (v[i], floor(v[i] * 2^32 / q_j)).  (A tile-major layout that makes the public-key kernel's pair loads
+// contiguous over the wave was measured 4 % SLOWER on that kernel, gpurun_out/ab_pk_tiled.log: at 256
+// VGPRs / 2 waves it is not the access pattern that limits it.)
 __global__ void k_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, int count)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,6 +681,8 @@ static hipError_t launch_enc(const DevParams &P, const DevTables &T, const EncAr
     size_t shmem   = (size_t)G::SLOTS * sizeof(double);
     // public-key kernel, n <= 4096: three u32 planes for the three-way NTT
     const size_t shmem_asym = LOGN <= 12 ? std::max(shmem, (size_t)3 * G::SLOTS * sizeof(uint32_t)) : shmem;
+    if (LOGN <= 12)  // + the wave-local transpose region behind the NTT plane: rows of 28 words
+        shmem = std::max(shmem, (size_t)(G::SLOTS + (G::N / 16) * 28) * sizeof(uint32_t));
     dim3 grid((unsigned)B), block(G::THREADS);
     switch (mode)
     {

@@ -100,6 +100,47 @@ __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
 }
 
 // ------------------------------------------------------------------------------------------
+// Tile layout -> "quad" layout, wave-local.  After the last NTT pass thread t owns the 16 CONSECUTIVE
+// coefficients 16t .. 16t+15, so every global access of the epilogue (a, key pairs, c0 / c1 stores) would
+// be 16-byte pieces at a 64- or 128-byte lane stride: 64 different cache lines per wave instruction,
+// 4-8 instructions per operand.  Measured on the fused symmetric kernel: the `a` and key-pair loads alone
+// cost 1.0 of its 3.6 ms (ablation, gpurun_out/abl_sym_loads.log) although the key table is L2-resident.
+// A wave's 64 tiles are the 1024 consecutive coefficients 1024 w .. 1024 w + 1023, so one wave-local LDS
+// transpose (4 ds_write_b128 + 4 ds_read_b128 per thread, no barrier: LDS executes a wave's accesses in
+// order) re-deals them so that in slot group i lane l holds coefficients 1024 w + 256 i + 4 l + (0..3):
+// every global instruction then covers 1 KiB contiguous.  Rows of 16 words are padded to STRIDE words
+// (multiple of 4): 28 makes the writes conflict-free and the reads cost 16 extra cycles per transpose, 16
+// (no pad) the other way round (96 / 0) -- tools/lds_conflicts.py.
+// ------------------------------------------------------------------------------------------
+template <int STRIDE>
+__device__ __forceinline__ void tile_to_quads(uint32_t (&x)[16], uint32_t *lds_region, int t)
+{
+    static_assert(STRIDE % 4 == 0 && STRIDE >= 16, "rows stay 16-byte aligned");
+    const int lane = t & 63;
+    uint32_t *w    = lds_region + (t >> 6) * (64 * STRIDE);
+    uint4 *row     = reinterpret_cast<uint4 *>(w + STRIDE * lane);
+#pragma unroll
+    for (int c = 0; c < 4; c++) row[c] = make_uint4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+    // the reads below fetch OTHER lanes' rows: keep the compiler from moving them above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int q   = 64 * i + lane;
+        const uint4 v = *reinterpret_cast<const uint4 *>(w + STRIDE * (q >> 2) + 4 * (q & 3));
+        x[4 * i] = v.x, x[4 * i + 1] = v.y, x[4 * i + 2] = v.z, x[4 * i + 3] = v.w;
+    }
+}
+
+// coefficient index (within the polynomial) of slot 4 i of thread t in quad layout
+__device__ __forceinline__ int quad_index(int t, int i)
+{
+    return ((t >> 6) << 10) + (i << 8) + ((t & 63) << 2);
+}
+
+// ------------------------------------------------------------------------------------------
 // IFFT pass: stages for local bits [B_LO, B_HI) of a tile at window C, ascending.
 // ------------------------------------------------------------------------------------------
 template <int LOGN, int C, int B_LO, int B_HI>

@@ -78,3 +78,31 @@ for logn in (10,11,12,13,14):
             for e in range(16):
                 tot+=conflicts([f(inv[16*(64*w+l)+e]&(n//2-1)) for l in range(64)],'r32')
         print(logn,name,tot)
+
+
+# ---- wave-local tile -> quad transpose (transform.cuh, tile_to_quads): rows of 16 words padded to STRIDE
+print("tile_to_quads: row stride, write conflicts (4 x ds_write_b128), read conflicts (4 x ds_read_b128) per wave")
+def wr_conf(addrs):  # ds_write_b128: 8x8 contiguous lanes, bank=(word)%32, 4 words per lane
+    extra=0
+    for g in range(0,64,8):
+        banks={}
+        for l in range(g,g+8):
+            for d in range(4):
+                banks.setdefault((addrs[l]+d)%32,set()).add(addrs[l]+d)
+        extra+=max(len(v) for v in banks.values())-1
+    return extra
+RG=[list(range(0,4))+list(range(12,16))+list(range(20,28)), list(range(4,12))+list(range(16,20))+list(range(28,32))]
+RG+= [[x+32 for x in g] for g in RG]
+def rd_conf(addrs):  # ds_read_b128: 4 groups of 16 lanes, bank %64
+    extra=0
+    for g in RG:
+        banks={}
+        for l in g:
+            for d in range(4):
+                banks.setdefault((addrs[l]+d)%64,set()).add(addrs[l]+d)
+        extra+=max(len(v) for v in banks.values())-1
+    return extra
+for stride in (16,20,24,28,36,40,44,52,68):
+    w=sum(wr_conf([stride*l+4*c for l in range(64)]) for c in range(4))
+    r=sum(rd_conf([stride*((64*i+l)>>2)+4*((64*i+l)&3) for l in range(64)]) for i in range(4))
+    print(stride,'write',w,'read',r)
