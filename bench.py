@@ -272,30 +272,40 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
     rec_bytes = 4 * npr * n
     # The root of a gathered run produces its block in place inside the gathered slab.
     gather_plan = None
-    c0_all = c1_all = None
+    c0_all = c1_all = c0 = c1 = None
     if want_gather and use_dist and world > 1:
-        slabs = 1 if mode == "encode" else 2
-        need_full = world * B * rec_bytes * slabs
-        need_local = B * rec_bytes * slabs
-        free = be.free_bytes()
-        margin = 6 << 30
-        if rank != 0 or free > need_full + margin:
-            gather_plan = "full"
-        elif mode == "sym" and free > world * B * rec_bytes + B * rec_bytes + margin:
-            gather_plan = "seed-compressed"        # c0 + 64-byte shareable seeds; c1 = expand(seed)
-        flag = torch.tensor([0 if gather_plan is None else (1 if gather_plan == "full" else 2)],
-                            dtype=torch.int64, device=be.dev)
+        # The root ALLOCATES the gathered slab(s) before anybody commits to a plan (a failed allocation
+        # after the plan was agreed would leave the other ranks waiting in the gather): full form, else
+        # the seed-compressed form (c0 + 64-byte shareable seeds; c1 = expand(seed)), else no gather.
+        code = 0
+        if rank == 0:
+            slabs = 1 if mode == "encode" else 2
+            margin = 6 << 30
+            for plan, need in (("full", world * B * rec_bytes * slabs),
+                               ("seed-compressed", world * B * rec_bytes + B * rec_bytes)):
+                if plan == "seed-compressed" and mode != "sym":
+                    continue
+                if be.free_bytes() < need + margin:
+                    continue
+                try:
+                    c0_all = torch.empty((world * B,) + rec, dtype=torch.int32, device=be.dev)
+                    if plan == "full" and mode != "encode":
+                        c1_all = torch.empty((world * B,) + rec, dtype=torch.int32, device=be.dev)
+                    elif mode != "encode":
+                        c1 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev)
+                    code = 1 if plan == "full" else 2
+                    break
+                except RuntimeError:                 # out of memory: drop what we got, try the smaller form
+                    c0_all = c1_all = c1 = None
+                    if not be.stub:
+                        torch.cuda.empty_cache()
+        flag = torch.tensor([code], dtype=torch.int64, device=be.dev)
         dist.broadcast(flag, src=0)                 # the root decides for everybody
         gather_plan = {0: None, 1: "full", 2: "seed-compressed"}[int(flag.item())]
-        del need_local
     if gather_plan and rank == 0:
-        c0_all = torch.empty((world * B,) + rec, dtype=torch.int32, device=be.dev)
-        c0 = c0_all[:B]
-        if mode != "encode" and gather_plan == "full":
-            c1_all = torch.empty((world * B,) + rec, dtype=torch.int32, device=be.dev)
+        c0 = c0_all[:B]                             # the root produces its block in place inside the slab
+        if c1_all is not None:
             c1 = c1_all[:B]
-        else:
-            c1 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev) if mode != "encode" else None
     else:
         c0 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev)
         c1 = torch.empty((B,) + rec, dtype=torch.int32, device=be.dev) if mode != "encode" else None
