@@ -22,12 +22,18 @@ Objects in the line beside the driver's contract fields:
                    for N > 1 the sharded C4 only.
   gather        -- N > 1: the final gather of ciphertext records to rank 0 timed separately
                    (`value_with_gather` = throughput with that time included).
+
+The contract measurement comes first and is protected: once the top-level workload has been timed,
+a deadline ($SE_BENCH_DEADLINE_S, default 600 s) covers everything that follows (the gather, the
+other configurations).  If that part raises, or does not finish in time (a rank lost inside a
+collective), rank 0 still prints the line it has, marked "incomplete", and every rank exits.
 """
 import argparse
 import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -57,6 +63,47 @@ KERNEL_NAMES = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform", "ternary":
                 "encode_encrypt": "k_encode_encrypt", "encode_rns": "k_encode_rns", "ntt_fuse": "k_ntt_fuse"}
 # kernels a stage timer may cover when a stage is more than one kernel (none today)
 STAGE_KERNELS = {}
+
+
+class Deadline:
+    """Keeps the best line measured so far; prints it from rank 0 and ends the process when the rest of
+    the run (gather, other configurations) does not finish in time.  Every rank arms its own timer with
+    the same delay, so the ranks of a job stuck in a collective all leave together."""
+
+    def __init__(self, rank):
+        self.rank, self.line, self.timer, self.lock, self.done = rank, None, None, threading.Lock(), False
+
+    def arm(self, seconds, line):
+        self.cancel()
+        self.line = line
+        self.timer = threading.Timer(seconds, self._fire, (seconds,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def update(self, line):
+        with self.lock:
+            self.line = line
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def printed(self):
+        """The complete line is out: from here on the timer only ends a process stuck in the shutdown."""
+        with self.lock:
+            self.done = True
+
+    def _fire(self, seconds):
+        with self.lock:
+            if self.done:
+                os._exit(0)
+            if self.rank == 0 and self.line is not None:
+                line = dict(self.line)
+                line["incomplete"] = (f"the part of the run after the top-level measurement did not finish "
+                                      f"within {seconds:.0f} s; fields measured until then are reported")
+                print(json.dumps(line), flush=True)
+        os._exit(0 if self.line is not None else 1)
 
 
 def stage_profile(prof, stage, field):
@@ -247,8 +294,11 @@ class Backend:
         return bench_values_device(B, n, self.dev, first=first)
 
 
-def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budget, want_gather, src_hash):
-    """One workload: timed region per the driver's contract, per-kernel profile, optional gather."""
+def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budget, want_gather, src_hash,
+               on_core=None):
+    """One workload: timed region per the driver's contract, per-kernel profile, optional gather.
+    `on_core(res)` is called with the contract fields + roofline as soon as they exist (before the gather
+    and the CPU baseline)."""
     import numpy as np
     import vectors as V
     torch = be.torch
@@ -395,39 +445,6 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
                 "dominant_kernel": dom, "kernels": kernels, "valu": valu,
                 "profile_source_sha256": src_hash}
 
-    gather = None
-    if gather_plan:
-        from seal_embedded_amd.sharding import gather_records
-        sizes = [B] * world
-        # untimed warm-up of the point-to-point connections (RCCL builds them on first use)
-        gather_records(c0[:1], dist, dst=0, out=c0_all[:world] if rank == 0 else None, sizes=[1] * world)
-        if rank == 0:
-            step()                                  # restore the root's record 0..world-1 region
-        fence()
-        g0 = time.perf_counter()
-        gather_records(c0, dist, dst=0, out=c0_all, sizes=sizes)
-        moved = (world - 1) * B * rec_bytes
-        if gather_plan == "full" and c1 is not None:
-            gather_records(c1, dist, dst=0, out=c1_all, sizes=sizes)
-            moved *= 2
-        elif gather_plan == "seed-compressed":
-            gather_records(ss, dist, dst=0, sizes=sizes)
-            moved += (world - 1) * B * 64
-        fence()
-        gsec = time.perf_counter() - g0
-        tg = torch.tensor([gsec], dtype=torch.float64, device=be.dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        gsec = float(tg.item())
-        if rank == 0 and os.environ.get("SE_BENCH_DUMP") and gather_plan == "full" and c1_all is not None:
-            import numpy as _np                    # test hook: the gathered slabs, rank order
-            _np.savez(os.environ["SE_BENCH_DUMP"], c0=c0_all.cpu().numpy(), c1=c1_all.cpu().numpy())
-        gather = {"form": gather_plan, "ms": gsec * 1e3, "bytes_into_root": moved, "GB/s": moved / gsec / 1e9,
-                  "value_with_gather": world * B / (ms_per_step * 1e-3 + gsec),
-                  "method": "batch_isend_irecv: every rank writes its block into its slice of the root's slab"}
-    elif want_gather and use_dist and world > 1:
-        gather = {"form": None, "skipped": "not enough free HBM on the root for the gathered slab"}
-
-    cpu = cpu_baseline(n, npr, mode, cpu_budget) if (want_cpu and rank == 0) else None
     unit = "ciphertexts/s" if mode != "encode" else "plaintexts/s"
     res = {
         "metric": "CKKS ciphertexts/s (batched encode+encrypt)" if mode != "encode"
@@ -439,8 +456,53 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         "config": {"workload": DESCR[name] + f", batch={B} per GPU", "n": n, "nprimes": npr, "mode": mode,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}",
                    "bytes_per_unit": bpu},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": None,
     }
+    if on_core is not None:
+        on_core(res)
+
+    gather = None
+    if gather_plan:
+        gather = {"form": gather_plan, "error": "did not finish"}
+        res["gather"] = gather
+    if gather_plan and os.environ.get("SE_BENCH_TEST_HANG") == "gather" and rank == world - 1:
+        time.sleep(3600)                            # test hook: a rank lost before the gather
+    if gather_plan:
+        try:
+            from seal_embedded_amd.sharding import gather_records
+            sizes = [B] * world
+            # untimed warm-up of the point-to-point connections (RCCL builds them on first use)
+            gather_records(c0[:1], dist, dst=0, out=c0_all[:world] if rank == 0 else None, sizes=[1] * world)
+            if rank == 0:
+                step()                                  # restore the root's record 0..world-1 region
+            fence()
+            g0 = time.perf_counter()
+            gather_records(c0, dist, dst=0, out=c0_all, sizes=sizes)
+            moved = (world - 1) * B * rec_bytes
+            if gather_plan == "full" and c1 is not None:
+                gather_records(c1, dist, dst=0, out=c1_all, sizes=sizes)
+                moved *= 2
+            elif gather_plan == "seed-compressed":
+                gather_records(ss, dist, dst=0, sizes=sizes)
+                moved += (world - 1) * B * 64
+            fence()
+            gsec = time.perf_counter() - g0
+            tg = torch.tensor([gsec], dtype=torch.float64, device=be.dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gsec = float(tg.item())
+            if rank == 0 and os.environ.get("SE_BENCH_DUMP") and gather_plan == "full" and c1_all is not None:
+                import numpy as _np                    # test hook: the gathered slabs, rank order
+                _np.savez(os.environ["SE_BENCH_DUMP"], c0=c0_all.cpu().numpy(), c1=c1_all.cpu().numpy())
+            gather = {"form": gather_plan, "ms": gsec * 1e3, "bytes_into_root": moved, "GB/s": moved / gsec / 1e9,
+                      "value_with_gather": world * B / (ms_per_step * 1e-3 + gsec),
+                      "method": "batch_isend_irecv: every rank writes its block into its slice of the root's slab"}
+        except Exception as e:                      # the measurement above must survive a failed gather
+            gather = {"form": gather_plan, "error": repr(e)}
+    elif want_gather and use_dist and world > 1:
+        gather = {"form": None, "skipped": "not enough free HBM on the root for the gathered slab"}
+
+    if want_cpu and rank == 0:
+        res["cpu_baseline"] = cpu_baseline(n, npr, mode, cpu_budget)
     if gather:
         res["gather"] = gather
     if hasattr(ctx, "close"):
@@ -485,8 +547,10 @@ def main():
     want_cpu = world == 1 and not args.no_cpu_baseline
     want_gather = world > 1 and not args.no_gather
     B = args.batch or WORKLOADS[args.workload][3]
+    deadline = Deadline(rank)
+    deadline_s = float(os.environ.get("SE_BENCH_DEADLINE_S", "600"))
     line = run_config(be, dist, args.workload, B, args.steps, args.warmup, rank, world, want_cpu, 10.0,
-                      want_gather, src_hash)
+                      want_gather, src_hash, on_core=lambda res: deadline.arm(deadline_s, res))
     if args.others is None:
         others = [] if args.workload != "c2" or args.batch else (["c3", "c4", "c5", "c1"] if world == 1 else ["c4"])
     else:
@@ -494,15 +558,21 @@ def main():
     extra = []
     for w in others:
         k = max(2, min(args.steps, 5))
-        extra.append(run_config(be, dist, w, WORKLOADS[w][3], k, min(args.warmup, 1) or 1, rank, world, want_cpu,
-                                4.0, want_gather, src_hash))
-    if extra:
+        try:
+            r = run_config(be, dist, w, WORKLOADS[w][3], k, min(args.warmup, 1) or 1, rank, world, want_cpu,
+                           4.0, want_gather, src_hash)
+        except Exception as e:                          # never lose the top-level line to a further config
+            r = {"config": {"workload": DESCR[w]}, "error": repr(e)}
+        extra.append(r)
         line["other_configs"] = extra
+        deadline.update(line)
     if rank == 0:
         print(json.dumps(line), flush=True)
+    deadline.printed()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    deadline.cancel()
 
 
 if __name__ == "__main__":

@@ -158,3 +158,19 @@ def test_bench_gathered_slab_is_single_process_order(tmp_path):
     ok, c0, c1 = Oracle(n, npr).encrypt_sym_batch(V.bench_values(total, n), *V.bench_seeds(total),
                                                   V.secret_key(n), nthreads=1)
     assert (got["c0"].view(np.uint32) == c0).all() and (got["c1"].view(np.uint32) == c1).all()
+
+
+def test_bench_line_survives_a_rank_lost_in_the_gather(tmp_path):
+    """The contract measurement is protected: when a rank never reaches the gather (test hook
+    SE_BENCH_TEST_HANG), every rank's deadline fires, rank 0 prints the line it has -- contract fields and
+    roofline complete, the gather marked unfinished, "incomplete" set -- and the job exits 0."""
+    os.environ["SE_BENCH_TEST_HANG"] = "gather"
+    os.environ["SE_BENCH_DEADLINE_S"] = "4"
+    try:
+        d = _run_bench(2, ["--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "2", "--others", "none"],
+                       tmp_path)
+    finally:
+        os.environ.pop("SE_BENCH_TEST_HANG", None)
+        os.environ.pop("SE_BENCH_DEADLINE_S", None)
+    assert "incomplete" in d and d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+    assert d["gather"]["form"] == "full" and "error" in d["gather"]
