@@ -119,17 +119,37 @@ __device__ __forceinline__ void ld_pairs(uint32_t (&w)[16], uint32_t (&wp)[16], 
 // inverse index map -> inverse FFT -> round to int64 (+ overflow status).  On return thread t owns
 // the plaintext coefficients k = t + (n/16)*e, e = 0..15, and the workgroup is synchronised.
 // ------------------------------------------------------------------------------------------
-template <int LOGN>
+//
+// MT = int64_t: the general form.  MT = int32_t: the FAST form of the fused kernel -- the coefficients are
+// only meaningful when `small` comes back true for every wave of the workgroup (|m| < 2 q_min - 64 < 2^31);
+// the caller hands every other plaintext to the general kernel (k_encode_encrypt_general).
+// The general kernel walks a list in a loop; seen as loop-invariant, the thread's table loads (twiddles,
+// gather map, roots, key rows) would be hoisted out of that loop and the kernel spills.  Its thread index
+// therefore passes through an opaque asm (a fresh value per iteration as far as the compiler knows).
+template <bool OPAQUE>
+__device__ __forceinline__ int thread_index()
+{
+    if constexpr (OPAQUE)
+    {
+        int t = threadIdx.x;
+        __asm__ volatile("" : "+v"(t));
+        return t;
+    }
+    else
+        return threadIdx.x;
+}
+
+template <int LOGN, typename MT>
 __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTables &T,
                                                  const float *values, uint8_t *status, size_t b,
-                                                 unsigned char *smem, int64_t (&m)[16], bool &small)
+                                                 unsigned char *smem, MT (&m)[16], bool &small)
 {
+    const int t = thread_index<sizeof(MT) == 8>();
     using G          = XformGeom<LOGN>;
     constexpr int N  = G::N;
     constexpr int TH = G::THREADS;
     double *plane    = reinterpret_cast<double *>(smem);
     float *sv        = reinterpret_cast<float *>(smem);
-    const int t      = threadIdx.x;
 
     // ckks_common.c:139-153 scatters values[i] to both conjugate slots; the map is a bijection
     // onto [0,n), so slot k is filled from values[inv_map[k] mod n/2].  The staging array is laid out
@@ -184,7 +204,12 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     }
     const int ok = !(amax > 9223372036854775808.0);
     small        = __all(amax < P.small_bound);
-    if (small)
+    if constexpr (sizeof(MT) == 4)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) m[e] = (int32_t)re[e];
+    }
+    else if (small)
     {
 #pragma unroll
         for (int e = 0; e < 16; e++) m[e] = (int64_t)(int32_t)re[e];
@@ -197,28 +222,62 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
         for (int e = 0; e < 16; e++)
             m[e] = (re[e] == 9223372036854775808.0) ? INT64_MIN : (int64_t)re[e];
     }
-    const int all_ok = __syncthreads_and(ok);
-    if (status && t == 0) status[b] = (uint8_t)all_ok;
+    if constexpr (sizeof(MT) == 4)
+    {
+        // fast form: `small` for the whole workgroup (it implies "no overflow"); a plaintext that is not
+        // small gets its status from the general kernel
+        small = __syncthreads_and(small) != 0;
+        if (status && t == 0 && small) status[b] = 1;
+    }
+    else
+    {
+        const int all_ok = __syncthreads_and(ok);
+        if (status && t == 0) status[b] = (uint8_t)all_ok;
+    }
 }
 
-template <int LOGN, int MODE>
-__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kModeAsym ? 2 : 3) : 1)) void k_encode_encrypt(DevParams P, DevTables T,
-                                                                          EncArgs A)
+// ------------------------------------------------------------------------------------------
+// The fused kernel comes in two forms.
+//   FAST (GENERAL = false): the plaintext is carried as int32 -- every |m + e| of a normal plaintext is
+//     below 2 q_min (|m| ~ scale * |value| ~ 2^30) -- which frees the 16 VGPRs of the high words and the
+//     code of the 64-bit reduction: 164 -> 126 VGPRs (n = 4096 symmetric: 4 workgroups per CU instead of
+//     3), the public-key form fits the quad-layout epilogue without spills.  A workgroup whose plaintext
+//     is NOT small (any wave) appends its index to A.general and leaves without writing outputs.
+//   GENERAL: int64 plaintext, the exact signed 64-bit reduction (reduce_pte_core, ckks_common.c:224-237);
+//     k_encode_encrypt_general walks the list the fast launch produced (normally empty: the launch costs
+//     a few microseconds).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+constexpr int enc_quad_stride()
 {
+    return MODE == kModeAsym ? 28 : 20;
+}
+
+template <int LOGN, int MODE, bool GENERAL>
+__device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables &T, const EncArgs &A,
+                                            const size_t b, unsigned char *smem)
+{
+    const int t = thread_index<GENERAL>();
     using G            = XformGeom<LOGN>;
     constexpr bool ASYM3 = LOGN <= 12;  // three-way NTT per prime (three LDS planes; spills at n = 8192)
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
 
-    const int t    = threadIdx.x;
-    const size_t b = blockIdx.x;
     const int np   = P.nprimes;
 
-    int64_t m[16];
+    using MT = typename std::conditional<GENERAL, int64_t, int32_t>::type;
+    MT m[16];
     bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
     encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
+    if constexpr (!GENERAL)
+    {
+        if (!small)   // workgroup-uniform in the fast form (encode_plaintext)
+        {
+            if (t == 0) A.general[1 + atomicAdd(A.general, 1u)] = (uint32_t)b;
+            return;
+        }
+    }
 
     // thread t now owns points k = t + (n/16)*e
     if constexpr (MODE == kModeSym)
@@ -242,13 +301,15 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
     {
         if (!A.c0) return;  // plain ckks_encode_base: only the int64 plaintext was requested
     }
-    // Outputs leave the kernel in quad layout (n <= 4096: the wave-local transpose region sits behind the
-    // NTT plane(s), so it needs no barrier against the next prime's exchanges)
-    // (the public-key kernel keeps the tile layout: three transposes per prime push it into spills and
-    // measure 0.5 % slower, gpurun_out/ab_quads2.log)
-    constexpr bool QUADS   = LOGN <= 12 && MODE != kModeAsym;
-    constexpr int QSTRIDE  = 28;
-    uint32_t *qlds         = lds32 + G::SLOTS;
+    // Outputs leave the kernel in quad layout (n <= 4096): the wave-local transpose region sits behind the
+    // NTT plane(s), so it needs no barrier against the next prime's exchanges.  Symmetric / encode-only:
+    // rows of 20 words (32 conflict cycles per transpose instead of the 16 of 28-word rows,
+    // tools/lds_conflicts.py) keep plane + region at 37 KiB -- 4 workgroups per CU.  Public-key form: rows
+    // of 28 behind the three planes (register-bound at 2 workgroups per CU either way); its general form
+    // keeps the tile layout (three transposes beside the int64 plaintext spill).
+    constexpr bool QUADS   = LOGN <= 12 && (MODE != kModeAsym || !GENERAL);
+    constexpr int QSTRIDE  = enc_quad_stride<MODE>();
+    uint32_t *qlds         = lds32 + (MODE == kModeAsym ? 3 : 1) * G::SLOTS;
     auto to_quads = [&](uint32_t (&v)[16]) {
         if constexpr (QUADS) tile_to_quads<QSTRIDE>(v, qlds, t);
     };
@@ -277,25 +338,30 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
             }
             reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
+            to_quads(uh);
             {
                 // c1 = pk1 . u_hat + NTT(e1)   (:251)
-                uint32_t w[16], wp[16], out[16];
-                ld_pairs<false>(w, wp, T.pk1 + kb, t);
+                uint32_t w[16], wp[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) y[e] = canon4(y[e], q, two_q);
+                to_quads(y);
+                ld_pairs<QUADS>(w, wp, T.pk1 + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
-                    out[e]      = csub(pr + canon4(y[e], q, two_q), q);
+                    y[e]        = csub(pr + y[e], q);
                 }
-                st_poly<QUADS>(A.c1 + pb, out, t);
+                st_poly<QUADS>(A.c1 + pb, y, t);
             }
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+            to_quads(x);
             if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, t);
             {
                 // c0 = pk0 . u_hat + NTT(m + e0)   (:255)
                 uint32_t w[16], wp[16], out[16];
-                ld_pairs<false>(w, wp, T.pk0 + kb, t);
+                ld_pairs<QUADS>(w, wp, T.pk0 + kb, t);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
@@ -356,7 +422,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
         else
         {
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
-            reduce_signed16<MODE != kModeSym>(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
+            reduce_signed16(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
                                                                           // symmetric kernel keeps the exact form
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
@@ -382,6 +448,36 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (LOGN <= 12 ? (MODE == kM
                 st_poly<QUADS>(A.c0 + pb, x, t);
             }
         }
+    }
+}
+
+// workgroups per CU the register budget is set for (n <= 4096: 256 threads = one wave per SIMD each)
+template <int LOGN, int MODE, bool GENERAL>
+constexpr int enc_blocks()
+{
+    if (LOGN > 12) return 1;
+    if (MODE == kModeAsym) return 2;   // 3 (with the transpose region aliased) spills: 5.45 -> 7.07 ms
+    return GENERAL ? 3 : 4;
+}
+
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (enc_blocks<LOGN, MODE, false>()))
+void k_encode_encrypt(DevParams P, DevTables T, EncArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    encrypt_one<LOGN, MODE, false>(P, T, A, blockIdx.x, smem);
+}
+
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (enc_blocks<LOGN, MODE, true>()))
+void k_encode_encrypt_general(DevParams P, DevTables T, EncArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t count = A.general[0];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x)
+    {
+        encrypt_one<LOGN, MODE, true>(P, T, A, A.general[1 + i], smem);
+        __syncthreads();
     }
 }
 
@@ -673,37 +769,51 @@ hipError_t launch_reduce_small(const DevParams &P, const int8_t *e, uint32_t *ou
 // ------------------------------------------------------------------------------------------
 // launchers (called from se_context.cpp)
 // ------------------------------------------------------------------------------------------
+template <int LOGN, int MODE>
+static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const EncArgs &A, size_t B,
+                                  hipStream_t st)
+{
+    using G             = XformGeom<LOGN>;
+    const size_t planes = (size_t)G::SLOTS * sizeof(double);   // the IFFT's two f64 half-planes
+    const size_t quads  = (size_t)(G::N / 16) * enc_quad_stride<MODE>() * sizeof(uint32_t);
+    // n <= 4096: one u32 NTT plane (public key: three, for the three-way NTT) + the transpose region
+    // behind it (not in the general public-key form)
+    size_t shmem_fast = planes, shmem_gen = planes;
+    if (LOGN <= 12)
+    {
+        const size_t ntt_planes = (size_t)(MODE == kModeAsym ? 3 : 1) * G::SLOTS * sizeof(uint32_t);
+        shmem_fast = std::max(planes, ntt_planes + quads);
+        shmem_gen  = MODE == kModeAsym ? std::max(planes, ntt_planes) : shmem_fast;
+    }
+    hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, MODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast);
+    hipLaunchKernelGGL((k_encode_encrypt<LOGN, MODE>), dim3((unsigned)B), dim3(G::THREADS), shmem_fast, st, P, T,
+                       A);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the plaintexts the fast form declined (normally none: the workgroups read a zero count and leave)
+    const unsigned cus  = P.num_cus ? P.num_cus : 256u;
+    const unsigned grid = (unsigned)std::min<size_t>(B, (size_t)4 * cus);
+    (void)hipFuncSetAttribute((const void *)k_encode_encrypt_general<LOGN, MODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_gen);
+    hipLaunchKernelGGL((k_encode_encrypt_general<LOGN, MODE>), dim3(grid), dim3(G::THREADS), shmem_gen, st, P,
+                       T, A);
+    return hipGetLastError();
+}
+
 template <int LOGN>
 static hipError_t launch_enc(const DevParams &P, const DevTables &T, const EncArgs &A, int mode,
                              size_t B, hipStream_t st)
 {
-    using G        = XformGeom<LOGN>;
-    size_t shmem   = (size_t)G::SLOTS * sizeof(double);
-    // public-key kernel, n <= 4096: three u32 planes for the three-way NTT
-    const size_t shmem_asym = LOGN <= 12 ? std::max(shmem, (size_t)3 * G::SLOTS * sizeof(uint32_t)) : shmem;
-    if (LOGN <= 12)  // + the wave-local transpose region behind the NTT plane: rows of 28 words
-        shmem = std::max(shmem, (size_t)(G::SLOTS + (G::N / 16) * 28) * sizeof(uint32_t));
-    dim3 grid((unsigned)B), block(G::THREADS);
+    if (!A.general) return hipErrorInvalidValue;   // the context's list of declined plaintexts
     switch (mode)
     {
-        case kModeSym:
-            (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeSym>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeSym>), grid, block, shmem, st, P, T, A);
-            break;
-        case kModeAsym:
-            (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeAsym>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_asym);
-            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeAsym>), grid, block, shmem_asym, st, P, T, A);
-            break;
-        default:
-            (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, kModeEncodeOnly>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            hipLaunchKernelGGL((k_encode_encrypt<LOGN, kModeEncodeOnly>), grid, block, shmem, st, P,
-                               T, A);
-            break;
+        case kModeSym: return launch_enc_mode<LOGN, kModeSym>(P, T, A, B, st);
+        case kModeAsym: return launch_enc_mode<LOGN, kModeAsym>(P, T, A, B, st);
+        default: return launch_enc_mode<LOGN, kModeEncodeOnly>(P, T, A, B, st);
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_encode_encrypt(const DevParams &P, const DevTables &T, const EncArgs &A, int mode,

@@ -18,6 +18,8 @@ struct EncArgs
     uint32_t *ntt_pte;
     int64_t *pte;
     uint8_t *status;
+    uint32_t *general;   // fused kernel only: [1 + B] count + indices of the plaintexts the fast form
+                         // declined (not "small"), processed by k_encode_encrypt_general
 };
 struct UniformArgs
 {

@@ -71,40 +71,29 @@ __device__ __forceinline__ void ct_butterfly(uint32_t &x, uint32_t &y, uint32_t 
 // the encoder) says that every |m + e| of the wave is below 2 q_min - 43: then m + 2q is such a
 // representative -- ONE add per coefficient and prime instead of the ~10 operations of the signed Barrett
 // reduction.  Otherwise all lanes take the exact path (reduce_pte_core, ckks_common.c:224-237).
-// CHEAP = false keeps the exact 32-bit signed reduction on the small path as well: the fused symmetric
-// kernel measures 19 % SLOWER with the single add (3.60 -> 4.29 ms per 65 536; the shorter prologue
-// changes the schedule around its `a` / key loads and adds spills), the encode-only, public-key and
-// split kernels faster (C5 -2.7 %, C3 -1 %), so each instantiation picks its form.
-template <bool CHEAP = true>
 __device__ __forceinline__ void reduce_signed16(const int64_t (&m)[16], uint32_t (&x)[16], uint32_t q,
                                                 uint32_t cr_hi, uint32_t cr_lo, bool small)
 {
     if (small)
     {
-        if constexpr (CHEAP)
-        {
-            const uint32_t two_q = q << 1;
+        const uint32_t two_q = q << 1;
 #pragma unroll
-            for (int e = 0; e < 16; e++) x[e] = (uint32_t)(int32_t)m[e] + two_q;   // in (0, 4q)
-        }
-        else
-        {
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-            {
-                int32_t v    = (int32_t)m[e];
-                bool neg     = v < 0;
-                uint32_t mag = neg ? 0u - (uint32_t)v : (uint32_t)v;
-                uint32_t r   = barrett32(mag, q, cr_hi);
-                x[e]         = neg ? q - r : r;
-            }
-        }
+        for (int e = 0; e < 16; e++) x[e] = (uint32_t)(int32_t)m[e] + two_q;   // in (0, 4q)
     }
     else
     {
 #pragma unroll
         for (int e = 0; e < 16; e++) x[e] = reduce_signed(m[e], q, cr_hi, cr_lo);
     }
+}
+
+// the fast fused kernel's plaintext (int32: every coefficient small by construction)
+__device__ __forceinline__ void reduce_signed16(const int32_t (&m)[16], uint32_t (&x)[16], uint32_t q, uint32_t,
+                                                uint32_t, bool)
+{
+    const uint32_t two_q = q << 1;
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = (uint32_t)m[e] + two_q;   // in (0, 4q)
 }
 
 // Gentleman-Sande butterfly of the inverse NTT, inputs/outputs in [0,2q):

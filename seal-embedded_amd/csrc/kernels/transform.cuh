@@ -59,7 +59,7 @@ __device__ __forceinline__ int tile_index(int t, int e)
 // the gather of the encoder; verified conflict-free for every exchange of n = 1024 .. 16384 with the
 // lane-group model, tools/lds_conflicts.py.)
 template <int CA, int CB>
-__device__ __forceinline__ int lds_slot(int k)
+__host__ __device__ constexpr int lds_slot(int k)
 {
     constexpr int lo = CA < CB ? CA : CB, hi = CA < CB ? CB : CA;
     if constexpr (hi <= 4)
@@ -84,16 +84,28 @@ struct XformGeom
 
 // Re-deal 16 values per thread from tile layout C_FROM to tile layout C_TO through `lds`.
 // Leaves the workgroup synchronised and `lds` free for reuse.
+//
+// lds_slot() is additive over disjoint bit fields (shifts distribute over OR), so the slot of point
+// tile_index<C>(t, e) is slot(thread part) + slot(e << C): ONE base register per deal and sixteen
+// compile-time offsets that land in the instructions' immediate fields.  Written as slot(tile_index(t, e))
+// the compiler does not see this: it computed the 16 addresses of every deal separately and, in the fused
+// kernels, kept them in registers across the prime loop (64 VGPRs of addresses for the two NTT exchanges).
 template <int C_FROM, int C_TO, typename T>
 __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
 {
-#pragma unroll
-    for (int e = 0; e < 16; e++) lds[lds_slot<C_FROM, C_TO>(tile_index<C_FROM>(t, e))] = v[e];
+    T *wr = lds + lds_slot<C_FROM, C_TO>(tile_index<C_FROM>(t, 0));
+    static_for<0, 16>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        wr[lds_slot<C_FROM, C_TO>(e << C_FROM)] = v[e];
+    });
 #ifndef SEAMD_ABL_NO_BARRIERS
     __syncthreads();
 #endif
-#pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = lds[lds_slot<C_FROM, C_TO>(tile_index<C_TO>(t, e))];
+    const T *rd = lds + lds_slot<C_FROM, C_TO>(tile_index<C_TO>(t, 0));
+    static_for<0, 16>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        v[e] = rd[lds_slot<C_FROM, C_TO>(e << C_TO)];
+    });
 #ifndef SEAMD_ABL_NO_BARRIERS
     __syncthreads();
 #endif
@@ -330,19 +342,19 @@ __device__ __forceinline__ void redeal3(uint32_t (&a)[16], uint32_t (&b)[16], ui
                                         uint32_t *lds, int t)
 {
     constexpr int SL = XformGeom<LOGN>::SLOTS;
-#pragma unroll
-    for (int e = 0; e < 16; e++)
-    {
-        const int s = lds_slot<C_FROM, C_TO>(tile_index<C_FROM>(t, e));
-        lds[s] = a[e], lds[SL + s] = b[e], lds[2 * SL + s] = c[e];
-    }
+    uint32_t *wr = lds + lds_slot<C_FROM, C_TO>(tile_index<C_FROM>(t, 0));
+    static_for<0, 16>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        constexpr int s = lds_slot<C_FROM, C_TO>(e << C_FROM);
+        wr[s] = a[e], wr[SL + s] = b[e], wr[2 * SL + s] = c[e];
+    });
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 16; e++)
-    {
-        const int s = lds_slot<C_FROM, C_TO>(tile_index<C_TO>(t, e));
-        a[e] = lds[s], b[e] = lds[SL + s], c[e] = lds[2 * SL + s];
-    }
+    const uint32_t *rd = lds + lds_slot<C_FROM, C_TO>(tile_index<C_TO>(t, 0));
+    static_for<0, 16>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        constexpr int s = lds_slot<C_FROM, C_TO>(e << C_TO);
+        a[e] = rd[s], b[e] = rd[SL + s], c[e] = rd[2 * SL + s];
+    });
     __syncthreads();
 }
 

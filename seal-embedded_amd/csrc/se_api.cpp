@@ -209,12 +209,7 @@ int se_amd_encode_device(se_amd_ctx *ctx, const float *d_values, size_t B, int64
                          uint8_t *d_status, void *stream)
 {
     if (!ctx || !d_out || !d_values) return SE_ERR_INVALD_ARGUMENT;
-    if (B == 0) return SE_SUCCESS;
-    SEAMD_HIP(hipSetDevice(ctx->c.device));
-    seamd::EncArgs ea{d_values, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, d_status};
-    SEAMD_HIP(seamd::launch_encode_encrypt(ctx->c.dp, ctx->c.dt, ea, seamd::kModeEncodeOnly, B,
-                                           as_stream(stream)));
-    return SE_SUCCESS;
+    return ctx->c.encode_ntt(d_values, B, nullptr, d_out, d_status, as_stream(stream));
 }
 
 int se_amd_ntt_device(se_amd_ctx *ctx, size_t prime, uint32_t *d_polys, size_t count, void *stream)

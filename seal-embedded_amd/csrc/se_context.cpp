@@ -75,7 +75,7 @@ Context::~Context()
     for (auto &sp : sp_streams)
         if (sp && sp != aux_stream) (void)hipStreamDestroy(sp);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
-                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec,
+                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general,
                     d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -176,8 +176,22 @@ int Context::init(size_t n, size_t nprimes, int dev)
     return 0;
 }
 
+// The fused kernel's list of declined plaintexts (kernel_args.h, EncArgs::general): 4 bytes per plaintext.
+int Context::ensure_general(size_t B)
+{
+    if (B <= general_cap && d_general) return 0;
+    SEAMD_HIP(hipSetDevice(device));
+    SEAMD_HIP(hipDeviceSynchronize());
+    if (d_general) (void)hipFree(d_general);
+    d_general = nullptr, general_cap = 0;
+    SEAMD_HIP(hipMalloc((void **)&d_general, (B + 1) * sizeof(uint32_t)));
+    general_cap = B;
+    return 0;
+}
+
 int Context::ensure_scratch(size_t B, size_t rows)
 {
+    if (int rc = ensure_general(B)) return rc;
     // d_err / d_ucodes / d_ctr are per real ciphertext; the reject lists and speculation rows are
     // also needed by the virtual ciphertexts of the small-batch path, which need nothing else
     if (rows < B) rows = B;
@@ -513,7 +527,7 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
 
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
-    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
+    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general};
 
     const size_t chain_waves_per_cu = ((B + 63) / 64 + (size_t)num_cus - 1) / (size_t)num_cus;
     const bool split = split_mode == 1 || (split_mode == 2 && (hp.n >= 8192 || chain_waves_per_cu < 4));
@@ -684,7 +698,7 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
         if (!sp_streams[j]) SEAMD_HIP(hipStreamCreateWithFlags(&sp_streams[j], hipStreamNonBlocking));
 
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
-    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status};
+    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general};
 
     //   S   : U_0 (real ciphertexts) ───────────────┐ (wait all) select ► (wait A) N_0 .. N_{np-1}
     //   A   : cbd ► k_encode_rns ───────────────────┤
@@ -816,7 +830,8 @@ int Context::encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d
                    d_c1 + lo * np * n,
                    d_ntt_pte ? d_ntt_pte + lo * np * n : nullptr,
                    d_pte ? d_pte + lo * n : nullptr,
-                   d_status ? d_status + lo : nullptr};
+                   d_status ? d_status + lo : nullptr,
+                   d_general};
         stage_begin(3, st);
         SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeAsym, cb, st));
         stage_end(st);
@@ -824,17 +839,25 @@ int Context::encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d
     return 0;
 }
 
+// d_out NULL: plain ckks_encode_base (only the int64 plaintexts are written)
 int Context::encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_t *d_pte,
                         uint8_t *d_status, hipStream_t st)
 {
     if (B == 0) return 0;
-    if (!d_values || !d_out) return kErrInvalid;
-    SEAMD_HIP(hipSetDevice(device));
-    EncArgs ea{d_values, nullptr, nullptr, d_out, nullptr, nullptr, d_pte, d_status};
-    stage_begin(3, st);
-    SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeEncodeOnly, B, st));
-    stage_end(st);
-    return 0;
+    if (!d_values || (!d_out && !d_pte)) return kErrInvalid;
+    std::lock_guard<std::mutex> lk(mu);   // the list of declined plaintexts is context scratch
+    int rc = begin_call(st);
+    if (rc) return rc;
+    rc = ensure_general(B);
+    if (rc == 0)
+    {
+        EncArgs ea{d_values, nullptr, nullptr, d_out, nullptr, nullptr, d_pte, d_status, d_general};
+        stage_begin(3, st);
+        hipError_t e = launch_encode_encrypt(dp, dt, ea, kModeEncodeOnly, B, st);
+        if (e != hipSuccess) rc = hip_fail(e, "launch_encode_encrypt");
+        stage_end(st);
+    }
+    return end_call(st, rc);
 }
 
 }  // namespace seamd

@@ -69,6 +69,8 @@ struct Context
     // ... and the bytes their output rows may take (one n-word row per virtual ciphertext)
     size_t small_bytes = getenv("SE_AMD_SMALL_BYTES") ? (size_t)atoll(getenv("SE_AMD_SMALL_BYTES")) : ((size_t)1 << 30);
     hipStream_t sp_streams[kMaxPrimes] = {};
+    uint32_t *d_general = nullptr;  // [1 + general_cap] plaintexts the fast fused kernel declined (count, indices)
+    size_t general_cap  = 0;
     size_t scratch_cap = 0;   // ciphertexts d_err / d_ucodes / d_ctr hold
     size_t rows_cap    = 0;   // rows of d_rej / d_spec (>= scratch_cap: virtual ciphertexts need only these)
     uint32_t rej_cap   = 256;
@@ -108,6 +110,7 @@ struct Context
     ~Context();
     int init(size_t n, size_t nprimes, int device);
     int ensure_scratch(size_t B, size_t rows = 0);
+    int ensure_general(size_t B);
     int begin_call(hipStream_t st);
     int end_call(hipStream_t st, int rc);
     // u codes (0/1/2 per coefficient) and e1 of ciphertext 0 of the last asymmetric call (host out)

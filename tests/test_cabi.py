@@ -211,3 +211,31 @@ def test_host_tables_match_oracle_and_golden(pkg, shape):
         assert (t["intt_rw"][j, :, 1].astype(np.uint64) == (ir << np.uint64(32)) // np.uint64(q)).all()
     with pytest.raises(pkg.SealEmbeddedAmdError):
         pkg.host_tables(3000, 1)
+
+
+def test_hot_kernels_keep_their_register_budget():
+    """Regression guard for the register budgets the throughput numbers rest on (hipcc
+    -Rpass-analysis=kernel-resource-usage, tools/resource_usage.py): the fast fused kernels of
+    n <= 8192 and the split kernels do not spill, and at n = 4096 the symmetric / encode-only forms fit
+    4 workgroups per CU (<= 128 VGPRs), the public-key form 2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "resource_usage.py"), "encode_encrypt"],
+                         capture_output=True, text=True, timeout=900).stdout
+    rows = {}
+    for line in out.splitlines()[1:]:
+        f = line.split()
+        if len(f) >= 6:
+            rows[" ".join(f[:-5])] = (int(f[-5]), int(f[-3]), int(f[-2]))     # VGPRs, scratch bytes, waves/SIMD
+    assert len(rows) > 30, out
+    for logn in (10, 11, 12, 13):
+        for mode in (0, 1, 2):
+            vgpr, scratch, occ = rows[f"k_encode_encrypt<{logn}, {mode}>"]
+            assert scratch == 0, (logn, mode, scratch)
+    for mode in (0, 2):
+        assert rows[f"k_encode_encrypt<12, {mode}>"][0] <= 128 and rows[f"k_encode_encrypt<12, {mode}>"][2] >= 4
+    assert rows["k_encode_encrypt<12, 1>"][2] >= 2
+    for k in ("k_ntt_fuse<12, 0>", "k_ntt_fuse<14, 0>", "k_encode_rns<12, true>", "k_encode_rns<14, true>",
+              "k_encode_encrypt<14, 0>", "k_encode_encrypt<14, 2>"):
+        assert rows[k][1] == 0, (k, rows[k])

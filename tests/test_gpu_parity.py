@@ -664,6 +664,53 @@ def test_magnitude_classes_through_every_path(env, n, npr):
                 assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all(), (split, b)
 
 
+@pytest.mark.parametrize("n,npr,B,large_every", [(1024, 1, 2600, 1), (2048, 1, 1500, 2), (4096, 3, 1300, 3)])
+def test_declined_plaintexts_take_the_general_kernel(env, n, npr, B, large_every):
+    """The fused kernel is two launches: the fast form (int32 plaintext) declines every plaintext with a
+    coefficient >= 2 q_min - 64 and queues it for k_encode_encrypt_general, which walks the queue with a
+    grid of 4 workgroups per CU.  Batches in which every / every 2nd / every 3rd plaintext is too large
+    (more queued plaintexts than that grid has workgroups at n = 1024 and 2048) must equal the oracle on
+    all three entries, element for element."""
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    o = Oracle(n, npr)
+    nth = pyoracle.host_threads()
+    two_q = 2.0 * min(o.q)
+    vals = V.bench_values(B, n, first=77).copy()     # |value| <= 25.5
+    vals *= min(1.0, 0.25 * two_q / (o.p.scale * 25.5))   # n = 2048: scale 2^25 over a 27-bit prime
+    vals[::large_every] *= 100.0                    # far above 2 q_min
+    assert np.abs(o.encode(vals[0])[1]).max() > two_q and (large_every == 1 or
+                                                            np.abs(o.encode(vals[1])[1]).max() < two_q - 64)
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=5)
+    ctx.set_secret_key(sk)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    ss, sd = V.bench_seeds(B, first=31337)
+    dv, dss, dsd = dev_t(env, vals), dev_t(env, ss), dev_t(env, sd)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.set_pipeline(1, 0)                           # the fused symmetric kernel at every degree
+    ctx.encrypt_sym(dv, dss, dsd, c0, c1, status=st)
+    torch.cuda.synchronize()
+    ok, e0, e1 = o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=nth)
+    assert ok and bool(st.all())
+    assert np.array_equal(host_u32(c0), e0) and np.array_equal(host_u32(c1), e1)
+    c0.zero_(), c1.zero_(), st.zero_()
+    ctx.encrypt_asym(dv, dsd, c0, c1, status=st)
+    torch.cuda.synchronize()
+    ok, e0, e1 = o.encrypt_asym_batch(vals, sd, pk0, pk1, nthreads=nth)
+    assert ok and bool(st.all())
+    assert np.array_equal(host_u32(c0), e0) and np.array_equal(host_u32(c1), e1)
+    c0.zero_(), st.zero_()
+    ctx.encode_ntt(dv, c0, status=st)
+    torch.cuda.synchronize()
+    ok, e0 = o.encode_ntt_batch(vals, nthreads=nth)
+    assert ok and bool(st.all()) and np.array_equal(host_u32(c0), e0)
+
+
 @pytest.mark.parametrize("n,npr,B", [(4096, 3, 1), (4096, 3, 5), (4096, 2, 16), (8192, 6, 2), (16384, 6, 1),
                                        (16384, 3, 2), (16384, 13, 1)])
 def test_small_batch_prime_speculation(env, n, npr, B):
