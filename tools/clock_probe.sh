@@ -3,8 +3,9 @@
 # (run on the GPU box: gpurun -- 'bash tools/clock_probe.sh > gpurun_out/clock.log 2>&1')
 cd "$(dirname "$0")/.."
 for w in ${CLOCK_WL:-c2 c3 c5}; do
+  steps=${CLOCK_STEPS:-$([ $w = c5 ] && echo 600 || echo 2500)}
   echo "== $w"
-  python bench.py --steps ${CLOCK_STEPS:-400} --warmup 2 --workload $w --no-cpu-baseline --others none > /tmp/clk_$w.json 2>/dev/null &
+  python bench.py --steps $steps --warmup 2 --workload $w --no-cpu-baseline --others none > /tmp/clk_$w.json 2>/dev/null &
   pid=$!
   sleep ${CLOCK_DELAY:-14}
   for i in 1 2 3 4 5 6; do
