@@ -664,6 +664,43 @@ def test_magnitude_classes_through_every_path(env, n, npr):
                 assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all(), (split, b)
 
 
+def test_chain_kernels_in_their_1024_thread_form(env):
+    """The per-ciphertext chain kernels (uniform `a`, ternary `u`) exist in two instantiations: up to 8
+    waves per workgroup (256-VGPR budget, every BASELINE shape) and up to 16 (batches beyond
+    8 x 64 x CUs per launch, 128-VGPR budget).  A batch of 140 000 at n = 1024 takes the second form in
+    both the symmetric and the public-key path; every ciphertext is compared with the oracle."""
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr, B = 1024, 1, 140000
+    o = Oracle(n, npr)
+    nth = pyoracle.host_threads()
+    vals = V.bench_values(B, n, first=5)
+    ss, sd = V.bench_seeds(B, first=999)
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=11)
+    ctx.set_secret_key(sk)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    dv, dss, dsd = dev_t(env, vals), dev_t(env, ss), dev_t(env, sd)
+    c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    c1 = torch.zeros_like(c0)
+    st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    for split in (0, 1):
+        ctx.set_pipeline(1, split)
+        c0.zero_(), c1.zero_()
+        ctx.encrypt_sym(dv, dss, dsd, c0, c1, status=st)
+        torch.cuda.synchronize()
+        _compare_all_with_oracle(c0, c1, lambda lo, hi: o.encrypt_sym_batch(vals[lo:hi], ss[lo:hi], sd[lo:hi], sk,
+                                                                           nthreads=nth), B, chunk=35000)
+    c0.zero_(), c1.zero_()
+    ctx.encrypt_asym(dv, dsd, c0, c1, status=st)
+    torch.cuda.synchronize()
+    _compare_all_with_oracle(c0, c1, lambda lo, hi: o.encrypt_asym_batch(vals[lo:hi], sd[lo:hi], pk0, pk1,
+                                                                        nthreads=nth), B, chunk=35000)
+    assert bool(st.all())
+
+
 @pytest.mark.parametrize("n,npr,B,large_every", [(1024, 1, 2600, 1), (2048, 1, 1500, 2), (4096, 3, 1300, 3)])
 def test_declined_plaintexts_take_the_general_kernel(env, n, npr, B, large_every):
     """The fused kernel is two launches: the fast form (int32 plaintext) declines every plaintext with a
