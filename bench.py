@@ -437,7 +437,9 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         floor_ms = insts * 4.0 / simds / VALU_CLOCK_HZ * 1e3
         valu = {"bound": "valu", "wave_insts_per_step": insts, "simds": simds, "clock_hz": VALU_CLOCK_HZ,
                 "floor_ms": floor_ms, "frac": floor_ms / ms_per_step,
-                "note": "wave64 VALU instruction = 4 SIMD cycles; floor = insts x 4 / SIMDs / clock"}
+                "note": "wave64 VALU instruction = 4 SIMD cycles; floor = insts x 4 / SIMDs / clock (nominal 2.4 GHz; "
+                        "the chip sustains 2.2-2.3 GHz under these loads, and v_xor/v_add/v_sub issue up to 1.7x "
+                        "faster than 4 cycles, so the figure is an estimate of the issue bound, not a hard floor)"}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "scope": "whole step: bytes_per_unit x batch / ms_per_step",
