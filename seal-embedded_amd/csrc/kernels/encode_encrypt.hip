@@ -170,8 +170,9 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     __syncthreads();
     double re[16], im[16];
     {
-        const uint4 *mp = reinterpret_cast<const uint4 *>(T.gather_map + 16 * t);
-        uint4 m0 = mp[0], m1 = mp[1];
+        // [2][n/16] uint4: half h of thread t's 16 entries at row h -- a wave load covers 1 KiB contiguous
+        const uint4 *mp = reinterpret_cast<const uint4 *>(T.gather_map);
+        uint4 m0 = mp[t], m1 = mp[TH + t];
         uint32_t packed[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
         for (int e = 0; e < 16; e++)
@@ -317,7 +318,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     {
         const uint32_t q = P.q[j], two_q = q << 1;
         const uint32_t crh = P.cr_hi[j], crl = P.cr_lo[j];
-        const uint32_t *RW = T.ntt_rw + (size_t)2 * N * j;
+        const uint32_t *RW = T.ntt_rw + 2 * xform_table_len(N) * j;
         const size_t pb    = (b * np + j) * N;            // this polynomial in the [ct][prime][coeff] slabs
         const size_t kb    = (size_t)2 * N * j;           // this prime's rows of the (value, shoup) key tables
         uint32_t x[16];
@@ -556,7 +557,7 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
         load_quads(a, A.c1 + (b * np + j) * N, t);
         if constexpr (!LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
     }
-    ntt_tiles<LOGN>(x, T.ntt_rw + (size_t)2 * N * j, q, lds32, t);
+    ntt_tiles<LOGN>(x, T.ntt_rw + 2 * xform_table_len(N) * j, q, lds32, t);
     if constexpr (MODE == kModeSym && LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_ntt_polys(DevParam
     uint32_t x[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = poly[(e << CTOP) + t];
-    ntt_tiles<LOGN>(x, T.ntt_rw + (size_t)2 * N * j, q, lds32, t);
+    ntt_tiles<LOGN>(x, T.ntt_rw + 2 * xform_table_len(N) * j, q, lds32, t);
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
     store16(poly + 16 * t, x);

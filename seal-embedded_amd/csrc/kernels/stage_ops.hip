@@ -271,7 +271,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_lower_sym_prime(De
     const size_t b   = blockIdx.x;
     const int j      = A.j;
     const uint32_t q = P.q[j], two_q = q << 1, crh = P.cr_hi[j], crl = P.cr_lo[j];
-    const uint32_t *RW = T.ntt_rw + (size_t)2 * N * j;
+    const uint32_t *RW = T.ntt_rw + 2 * xform_table_len(N) * j;
     const size_t off   = b * N + 16 * t;
     const uint8_t *key = A.s_small + b * (size_t)A.s_stride;
     const uint32_t *ap = A.a + b * (size_t)(A.a_stride ? A.a_stride : N) + 16 * t;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_lower_asym_prime(D
     const size_t b   = blockIdx.x;
     const int j      = A.j;
     const uint32_t q = P.q[j], two_q = q << 1, crh = P.cr_hi[j], crl = P.cr_lo[j];
-    const uint32_t *RW = T.ntt_rw + (size_t)2 * N * j;
+    const uint32_t *RW = T.ntt_rw + 2 * xform_table_len(N) * j;
     const size_t off   = b * N + 16 * t;
 
     uint32_t uh[16], x[16], p1[16], p0[16];

@@ -98,17 +98,13 @@ __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
         constexpr int e = decltype(ec)::value;
         wr[lds_slot<C_FROM, C_TO>(e << C_FROM)] = v[e];
     });
-#ifndef SEAMD_ABL_NO_BARRIERS
     __syncthreads();
-#endif
     const T *rd = lds + lds_slot<C_FROM, C_TO>(tile_index<C_TO>(t, 0));
     static_for<0, 16>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         v[e] = rd[lds_slot<C_FROM, C_TO>(e << C_TO)];
     });
-#ifndef SEAMD_ABL_NO_BARRIERS
     __syncthreads();
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -169,12 +165,9 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
         constexpr int groups = 1 << (3 - b);  // distinct twiddles this thread needs in this stage
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const int idx   = h + ((thi << (3 - b)) | g);
-#ifdef SEAMD_ABL_NO_ROOT_LOADS
-            const double2 w = make_double2(1.0 + idx, 0.5);
-#else
+            // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
+            const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
-#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
@@ -206,11 +199,10 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
     constexpr int N = 1 << LOGN;
     static_for<0, 4>([&](auto bc) {
         constexpr int b      = decltype(bc)::value;
-        constexpr int h      = N >> (b + 1);
         constexpr int groups = 1 << (3 - b);
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const int idx   = h + ((t << (3 - b)) | g);
+            const int idx   = N + ((8 >> b) - 1 + g) * (N / 16) + t;   // thread-major copy (se_types.h)
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int r  = decltype(rc)::value;
@@ -287,12 +279,9 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
         constexpr int groups = 1 << (3 - b);
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const int idx   = h + ((thi << (3 - b)) | g);
-#ifdef SEAMD_ABL_NO_ROOT_LOADS
-            const uint2 rw  = make_uint2(12345u + idx, 54321u);
-#else
+            // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
+            const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
             const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
-#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
@@ -371,7 +360,7 @@ __device__ __forceinline__ void ntt_pass3(uint32_t (&x)[16], uint32_t (&y)[16], 
         constexpr int groups = 1 << (3 - b);
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const int idx   = h + ((thi << (3 - b)) | g);
+            const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
             const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;

@@ -123,20 +123,35 @@ int Context::init(size_t n, size_t nprimes, int dev)
     host_index_map(hp, index_map, inv);
     std::vector<double> w;
     host_ifft_twiddles(hp, w);
-    std::vector<uint32_t> rw_all(2 * n * nprimes), rw;
+    // every table is followed by the thread-major copy of its window-0 entries (se_types.h)
+    const size_t tl = xform_table_len(n), th = n / 16;
+    auto append_thread_major = [&](auto *tab) {   // tab: [tl][2], first n pairs filled
+        for (int b = 0; b < 4; b++)
+            for (size_t g = 0; g < ((size_t)1 << (3 - b)); g++)
+                for (size_t t = 0; t < th; t++)
+                {
+                    const size_t src = (n >> (b + 1)) + (t << (3 - b)) + g;
+                    const size_t dst = n + ((8u >> b) - 1 + g) * th + t;
+                    tab[2 * dst] = tab[2 * src], tab[2 * dst + 1] = tab[2 * src + 1];
+                }
+    };
+    w.resize(2 * tl);
+    append_thread_major(w.data());
+    std::vector<uint32_t> rw_all(2 * tl * nprimes), rw;
     for (size_t j = 0; j < nprimes; j++)
     {
         host_ntt_root_pairs(hp, j, rw);
         // the device table holds (-root mod 2^32, shoup(root)): the forward butterfly then needs no
         // separate negation (ct_butterfly, modarith.cuh)
         for (size_t i = 0; i < n; i++) rw[2 * i] = 0u - rw[2 * i];
-        memcpy(rw_all.data() + 2 * n * j, rw.data(), 2 * n * sizeof(uint32_t));
+        memcpy(rw_all.data() + 2 * tl * j, rw.data(), 2 * n * sizeof(uint32_t));
+        append_thread_major(rw_all.data() + 2 * tl * j);
     }
     SEAMD_HIP(hipMalloc((void **)&d_inv_map, n * sizeof(uint16_t)));
-    SEAMD_HIP(hipMalloc((void **)&d_ifft_w, 2 * n * sizeof(double)));
+    SEAMD_HIP(hipMalloc((void **)&d_ifft_w, w.size() * sizeof(double)));
     SEAMD_HIP(hipMalloc((void **)&d_ntt_rw, rw_all.size() * sizeof(uint32_t)));
     SEAMD_HIP(hipMemcpy(d_inv_map, inv.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
-    SEAMD_HIP(hipMemcpy(d_ifft_w, w.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
+    SEAMD_HIP(hipMemcpy(d_ifft_w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
     SEAMD_HIP(hipMemcpy(d_ntt_rw, rw_all.data(), rw_all.size() * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
     SEAMD_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
@@ -164,8 +179,13 @@ int Context::init(size_t n, size_t nprimes, int dev)
     }
     {
         std::vector<uint16_t> gather(n);
+        // point k = 16 t + e is entry e % 8 of the uint4 at [e / 8][t]
         for (size_t k = 0; k < n; k++)
-            gather[k] = (uint16_t)sv_slot((uint32_t)(inv[k] & (n / 2 - 1)), (uint32_t)hp.logn);
+        {
+            const size_t t = k >> 4, e = k & 15;
+            gather[((e >> 3) * (n / 16) + t) * 8 + (e & 7)] =
+                (uint16_t)sv_slot((uint32_t)(inv[k] & (n / 2 - 1)), (uint32_t)hp.logn);
+        }
         SEAMD_HIP(hipMalloc((void **)&d_gather, n * sizeof(uint16_t)));
         SEAMD_HIP(hipMemcpy(d_gather, gather.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
         dt.gather_map = d_gather;

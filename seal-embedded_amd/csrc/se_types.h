@@ -31,15 +31,28 @@ struct DevParams
 struct DevTables
 {
     const uint16_t *inv_map;   // [n]   x[k] <- values[inv_map[k] & (n/2-1)]
-    const double *ifft_w;      // [n][2] (re, im) of W[t], t = h + j  (fft.c:129)
-    const uint32_t *ntt_rw;    // [np][n][2] (-root mod 2^32, shoup(root)) indexed h + g (ntt.c:40-52)
+    const double *ifft_w;      // [n][2] (re, im) of W[t], t = h + j  (fft.c:129), then the thread-major copy of
+                               // the window-0 entries [15][n/16][2] (xform_table_len)
+    const uint32_t *ntt_rw;    // [np][ (-root mod 2^32, shoup(root)) indexed h + g (ntt.c:40-52): [n][2], then the
+                               // thread-major copy of the window-0 entries [15][n/16][2] ]
     const uint32_t *s_hat;     // [np][n][2] (NTT(s), shoup)       sym
     const uint32_t *pk0;       // [np][n][2] (pk0, shoup)          asym
     const uint32_t *pk1;       // [np][n][2] (pk1, shoup)          asym
     const uint32_t *intt_rw;   // [np][n][2] (psi^-bitrev(h+g), shoup) indexed h + g (intt.c:26-58)
     const uint16_t *index_map; // [n] forward index map (decode slot pick)
-    const uint16_t *gather_map; // [n] encoder gather: LDS position (sv_slot) of the value that feeds point k
+    const uint16_t *gather_map; // encoder gather: LDS position (sv_slot) of the value that feeds point 16 t + e,
+                                // stored [e / 8][t][e % 8] (one uint4 per thread and half)
 };
+
+// Root tables carry a second, thread-major copy of the entries a pass over window 0 reads (transform.cuh:
+// thread t needs entry h_b + (t << (3 - b)) + g for the stages b = 3..0, g < 2^(3-b), i.e. 8 / 4 / 2 / 1
+// CONSECUTIVE entries per lane -- 64 different cache lines per wave load).  Row e = (8 >> b) - 1 + g of the
+// copy holds that entry for t = 0 .. n/16-1, so a wave load reads 64 consecutive entries.
+// Elements (pairs) of one table: n natural + 15 n/16 transposed.
+constexpr size_t xform_table_len(size_t n)
+{
+    return n + 15 * (n / 16);
+}
 
 // LDS position of values[i] in the encoder's staging array.  Thread t gathers, for each e, the value
 // feeding point 16t + e; over the 32 lanes of an LDS lane group those indices are i0 + 2^(logn-10) * h
