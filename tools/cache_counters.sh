@@ -15,7 +15,7 @@ for f in sorted(glob.glob('gpurun_out/cc_$W/set*.csv')):
     seen = set()
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0].replace('void ', '')
-        if 'seamd' not in k: continue
+        if 'seamd' not in k and 'copyBuffer' not in k: continue
         tot[k][row['Counter_Name']] += float(row['Counter_Value'])
 for k, d in tot.items():
     print(k)
