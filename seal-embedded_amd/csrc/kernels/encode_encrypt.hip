@@ -10,7 +10,8 @@
 //   ckks_encode_encrypt_asym (ckks_asym.c:205-286) incl. poly_*_mod_inpl (polymodarith.h:39-101)
 //
 // Data never leaves the CU between encode and the final store: the plaintext stays in VGPRs
-// (int64 x 16 per thread) across all primes; LDS is only the re-deal buffer of the transforms.
+// (int32 x 16 per thread in the fast form, int64 in the general form -- see encrypt_one) across all
+// primes; LDS is only the re-deal buffer of the transforms.
 // HBM traffic per ciphertext = values (2n B) + error bytes + a (read back, 4n*np) + c0 (4n*np).
 //
 // NTT(s) is a per-key constant: it is computed once when the key is set (k_ntt_polys below)
