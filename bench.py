@@ -141,14 +141,19 @@ def kernel_bytes_per_unit(mode, n, npr):
 
 
 def kernel_source_hash():
-    """SHA-256 over the kernel sources: profiles collected for other sources are not quoted."""
+    """SHA-256 over the kernel sources with comments and whitespace removed: profiles collected for other
+    CODE are not quoted, an edited comment does not orphan them."""
+    import re
     h = hashlib.sha256()
     kdir = os.path.join(ROOT, "seal-embedded_amd", "csrc", "kernels")
-    for name in sorted(os.listdir(kdir)):
-        if name.endswith((".hip", ".cuh", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(kdir, name), "rb").read())
-    h.update(open(os.path.join(ROOT, "seal-embedded_amd", "csrc", "se_types.h"), "rb").read())
+    files = [os.path.join(kdir, n) for n in sorted(os.listdir(kdir)) if n.endswith((".hip", ".cuh", ".h"))]
+    files.append(os.path.join(ROOT, "seal-embedded_amd", "csrc", "se_types.h"))
+    for path in files:
+        text = open(path, "r", encoding="utf-8", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)       # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                    # line comments (no '//' inside literals here)
+        h.update(os.path.basename(path).encode())
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
