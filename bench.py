@@ -523,8 +523,9 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: a step is ~9 ms; the first ~10 steps after an idle period run 2-3 % slower (clock ramp)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="batch per GPU (0 = workload default)")
     ap.add_argument("--others", default=None,
@@ -564,9 +565,9 @@ def main():
         others = [w for w in args.others.split(",") if w and w != "none"]
     extra = []
     for w in others:
-        k = max(2, min(args.steps, 5))
+        k = max(2, min(args.steps, 20))
         try:
-            r = run_config(be, dist, w, WORKLOADS[w][3], k, min(args.warmup, 1) or 1, rank, world, want_cpu,
+            r = run_config(be, dist, w, WORKLOADS[w][3], k, max(1, min(args.warmup, 4)), rank, world, want_cpu,
                            4.0, want_gather, src_hash)
         except Exception as e:                          # never lose the top-level line to a further config
             r = {"config": {"workload": DESCR[w]}, "error": repr(e)}
