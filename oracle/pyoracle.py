@@ -39,7 +39,8 @@ def build(ref=True):
         # the reference's own test functions relinked against the product library (tests/test_gpu_reftests.py)
         lib = os.path.join(os.path.dirname(HERE), "seal-embedded_amd", "lib", "libseal_embedded_amd.so")
         if os.path.exists(lib):
-            subprocess.check_call(["make", "-s", "-C", HERE, "reftests", "SE_REFERENCE_DIR=" + REFERENCE_DIR])
+            subprocess.check_call(["make", "-s", "-C", HERE, "reftests", "refbench",
+                                   "SE_REFERENCE_DIR=" + REFERENCE_DIR])
 
 
 class SeoParams(C.Structure):

@@ -61,3 +61,20 @@ def test_reference_test_function_passes_on_the_gpu_library(workdir, case):
     assert r.returncode == 0, f"rc={r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-1500:]}"
     assert f"REF_TEST_DONE {name} {n} {npr}" in r.stderr
     assert "Assertion" not in r.stderr and "Error!" not in r.stdout[-400:]
+
+
+BENCH_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_bench_gpu")
+
+
+@pytest.mark.parametrize("name", ["sym", "asym", "ifft", "ntt", "uniform", "ternary", "cbd"])
+def test_reference_benchmark_runs_on_the_gpu_library(workdir, name):
+    """The reference's OWN benchmark functions (device/bench/bench_*.c with its timer.c, `make -C oracle
+    refbench`) linked against the product library: they run to completion and print the reference's
+    timing lines (single-call latency of the lower surface; printed for the log, not asserted)."""
+    if not os.path.exists(BENCH_EXE):
+        pytest.skip("oracle/_ref/ref_bench_gpu not built (needs /root/reference at build time)")
+    r = subprocess.run([BENCH_EXE, name], cwd=workdir, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"rc={r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-1500:]}"
+    assert f"ref-bench {name} done" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if "avg" in l.lower() or "Runtime" in l or "us" in l]
+    print("\n".join(lines[-6:]))
