@@ -131,8 +131,8 @@ def kernel_bytes_per_unit(mode, n, npr):
         return {"uniform": 64 + poly,                   # seed in, a out
                 "cbd": 64 + n,                          # seed in, int8 error out
                 "encode_encrypt": 2 * n + n + poly + poly,   # values, e, a in; c0 out
-                "encode_rns": 2 * n + n + poly,         # values, e in; residues out
-                "ntt_fuse": poly + poly + poly}         # residues, a in; c0 out
+                "encode_rns": 2 * n + n + 4 * n,        # values, e in; ONE int32 row out (compact form)
+                "ntt_fuse": poly + poly + poly}         # that row (re-read per prime), a in; c0 out
     if mode == "asym":
         return {"ternary": 64 + n + 8,                  # seed in; codes + counter out
                 "cbd": 64 + 8 + 2 * n,                  # seed, counter in; e0 | e1 out

@@ -516,6 +516,22 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
 #pragma unroll
         for (int e = 0; e < 16; e++) A.pte[b * N + (e << CTOP) + t] = m[e];
     }
+    // A small plaintext (every |m + e| < 2 q_min: the normal case) crosses to k_ntt_fuse as ONE row of
+    // int32 -- parked in the c0 row of the LAST prime, which its own launch reads before it overwrites it --
+    // instead of np rows of residues: k_ntt_fuse forms the representative m + 2 q_j itself.  At n = 16384
+    // this kernel is HBM-bound (6 x 64 KiB of residues per plaintext against 48 KiB of inputs).
+    if (A.compact)
+    {
+        const bool compact = __syncthreads_and(small) != 0;
+        if (t == 0) A.compact[b] = compact ? 1 : 0;
+        if (compact)
+        {
+            uint32_t *dst = A.c0 + (b * np + (np - 1)) * N;
+#pragma unroll
+            for (int e = 0; e < 16; e++) dst[(e << CTOP) + t] = (uint32_t)(int32_t)m[e];
+            return;
+        }
+    }
     for (int j = 0; j < np; j++)
     {
         uint32_t x[16];
@@ -544,9 +560,14 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     const uint32_t q = P.q[j], two_q = q << 1;
     uint32_t *poly   = A.c0 + (b * np + j) * N;
 
+    // residues of this prime, or the compact int32 plaintext from the last prime's row (k_encode_rns):
+    // m + 2 q_j is a representative in (0, 4q) the NTT accepts (modarith.cuh, reduce_signed16)
+    const bool compact  = A.compact != nullptr && A.compact[b] != 0;
+    const uint32_t *src = compact ? A.c0 + (b * np + (np - 1)) * N : poly;
+    const uint32_t bias = compact ? two_q : 0u;
     uint32_t x[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = poly[(e << CTOP) + t];
+    for (int e = 0; e < 16; e++) x[e] = src[(e << CTOP) + t] + bias;
     // issue the epilogue operands now; they land while the NTT runs.  At n = 16384 only `a` (HBM) is
     // prefetched; the L2-resident s_hat pairs are fetched after the NTT to stay within 96 VGPRs.
     // All epilogue accesses are in quad layout (transform.cuh, tile_to_quads): 1 KiB contiguous per wave

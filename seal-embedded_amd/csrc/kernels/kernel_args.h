@@ -20,6 +20,9 @@ struct EncArgs
     uint8_t *status;
     uint32_t *general;   // fused kernel only: [1 + B] count + indices of the plaintexts the fast form
                          // declined (not "small"), processed by k_encode_encrypt_general
+    uint8_t *compact;    // split kernels only (optional): [B] k_encode_rns -> k_ntt_fuse, 1 = the plaintext
+                         // was small and travels as ONE int32 row (in c0's last prime row) instead of np
+                         // residue rows
 };
 struct UniformArgs
 {

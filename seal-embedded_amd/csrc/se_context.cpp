@@ -75,7 +75,7 @@ Context::~Context()
     for (auto &sp : sp_streams)
         if (sp && sp != aux_stream) (void)hipStreamDestroy(sp);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
-                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general,
+                    d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general, d_compact,
                     d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -221,14 +221,15 @@ int Context::ensure_scratch(size_t B, size_t rows)
     const size_t n = hp.n;
     if (B > scratch_cap)
     {
-        void *old[] = {d_err, d_ucodes, d_ctr};
+        void *old[] = {d_err, d_ucodes, d_ctr, d_compact};
         for (void *p : old)
             if (p) (void)hipFree(p);
-        d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr;
+        d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_compact = nullptr;
         scratch_cap = 0;
         SEAMD_HIP(hipMalloc((void **)&d_err, B * 2 * n));
         SEAMD_HIP(hipMalloc((void **)&d_ucodes, B * n));
         SEAMD_HIP(hipMalloc((void **)&d_ctr, B * sizeof(uint64_t)));
+        SEAMD_HIP(hipMalloc((void **)&d_compact, B));
         scratch_cap = B;
     }
     if (rows > rows_cap)
@@ -547,7 +548,7 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
 
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
-    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general};
+    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general, d_compact};
 
     const size_t chain_waves_per_cu = ((B + 63) / 64 + (size_t)num_cus - 1) / (size_t)num_cus;
     const bool split = split_mode == 1 || (split_mode == 2 && (hp.n >= 8192 || chain_waves_per_cu < 4));
@@ -718,7 +719,7 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
         if (!sp_streams[j]) SEAMD_HIP(hipStreamCreateWithFlags(&sp_streams[j], hipStreamNonBlocking));
 
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
-    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general};
+    EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general, d_compact};
 
     //   S   : U_0 (real ciphertexts) ───────────────┐ (wait all) select ► (wait A) N_0 .. N_{np-1}
     //   A   : cbd ► k_encode_rns ───────────────────┤

@@ -69,6 +69,7 @@ struct Context
     // ... and the bytes their output rows may take (one n-word row per virtual ciphertext)
     size_t small_bytes = getenv("SE_AMD_SMALL_BYTES") ? (size_t)atoll(getenv("SE_AMD_SMALL_BYTES")) : ((size_t)1 << 30);
     hipStream_t sp_streams[kMaxPrimes] = {};
+    uint8_t *d_compact  = nullptr;  // [scratch_cap] k_encode_rns -> k_ntt_fuse: plaintext b travels as one int32 row
     uint32_t *d_general = nullptr;  // [1 + general_cap] plaintexts the fast fused kernel declined (count, indices)
     size_t general_cap  = 0;
     size_t scratch_cap = 0;   // ciphertexts d_err / d_ucodes / d_ctr hold
