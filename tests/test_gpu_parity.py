@@ -664,6 +664,36 @@ def test_magnitude_classes_through_every_path(env, n, npr):
                 assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all(), (split, b)
 
 
+def test_contexts_release_their_device_memory(env):
+    """Create / use / destroy cycles leave the device's free memory where it was: every table, scratch
+    slab (incl. the ones grown by a larger batch), stream and event of a context is released by
+    se_amd_destroy."""
+    torch = env["torch"]
+    n, npr = 4096, 3
+    sk = V.secret_key(n)
+
+    def cycle(B):
+        ctx = env["pkg"].Context(n, npr)
+        ctx.set_secret_key(sk)
+        pk0, pk1 = ctx.gen_public_key(sk, SEED_PK, SEED_EP)
+        ctx.set_public_key(pk0, pk1)
+        vals = V.bench_values(B, n)
+        ss, sd = V.bench_seeds(B)
+        r = ctx.encrypt_sym_host(vals, ss, sd)
+        ra = ctx.encrypt_asym_host(vals, sd)
+        assert r["failed"] == 0 and bool(ra["status"].all())
+        ctx.close()
+
+    cycle(8)                                         # first use: runtime pools, code objects
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for B in (3, 700, 64, 700):
+        cycle(B)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free0 - free1) <= 8 << 20, (free0, free1)   # allocator granularity, not a leak per cycle
+
+
 def test_chain_kernels_in_their_1024_thread_form(env):
     """The per-ciphertext chain kernels (uniform `a`, ternary `u`) exist in two instantiations: up to 8
     waves per workgroup (256-VGPR budget, every BASELINE shape) and up to 16 (batches beyond
