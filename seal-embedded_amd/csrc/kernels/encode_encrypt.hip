@@ -158,9 +158,11 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     // LDS position directly.
     {
         const float4 *src = reinterpret_cast<const float4 *>(values + b * (N / 2));
+        static_assert((N / 8) % TH == 0, "every thread stages the same number of float4 pieces");
 #pragma unroll
-        for (int i = t; i < N / 8; i += TH)
+        for (int k = 0; k < (N / 8) / TH; k++)
         {
+            const int i    = t + k * TH;
             const float4 v = src[i];
             sv[sv_slot(4u * i, LOGN)]      = v.x;
             sv[sv_slot(4u * i + 1u, LOGN)] = v.y;
