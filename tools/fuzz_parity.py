@@ -34,15 +34,17 @@ while time.time() - t0 < budget:
         ctx.set_public_key(pk0, pk1)
         ctxs[key] = (ctx, o, sk, pk0, pk1)
     ctx, o, sk, pk0, pk1 = ctxs[key]
-    kind = rng.randrange(4)
+    kind = rng.randrange(5)
     if kind == 0:
         vals = V.bench_values(B, n, seed=case_seed)
     elif kind == 1:
         vals = (nr.standard_normal((B, n // 2)) * 3).astype(np.float32)
     elif kind == 2:
         vals = np.zeros((B, n // 2), dtype=np.float32); vals[:, nr.integers(0, n // 2)] = 1
-    else:
+    elif kind == 3:
         vals = nr.uniform(-30, 30, (B, n // 2)).astype(np.float32)
+    else:   # rows of mixed magnitude: the fast kernels decline some plaintexts of the batch, not others
+        vals = (nr.uniform(-30, 30, (B, n // 2)) * nr.choice([0.01, 1.0, 100.0], (B, 1))).astype(np.float32)
     ss = nr.integers(0, 256, (B, 64), dtype=np.uint8); sd = nr.integers(0, 256, (B, 64), dtype=np.uint8)
     ov, sp = rng.choice([(1, 2), (1, 2), (0, 0), (1, 0), (0, 1), (1, 1)])
     ctx.set_pipeline(ov, sp)
