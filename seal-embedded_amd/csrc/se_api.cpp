@@ -760,18 +760,43 @@ int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
         const size_t lo = B * d / ndev, hi = B * (d + 1) / ndev;
         se_amd_ctx *ctx = d == 0 ? g_ctx : g_more[d - 1];
         workers.emplace_back([&, d, lo, hi, ctx] {
+            // fault injection for the re-run path (tests): $SE_AMD_INJECT_SHARD_FAILURE = shard index
+            const char *inj = getenv("SE_AMD_INJECT_SHARD_FAILURE");
+            if (inj && *inj && (size_t)atol(inj) == d)
+            {
+                rcs[d]  = SE_ERR_NO_DEVICE;
+                errs[d] = "injected shard failure";
+                return;
+            }
             rcs[d] = run(ctx, lo, hi - lo);
             if (rcs[d] < 0) errs[d] = se_amd_last_error();  // thread-local: carry it to the caller
         });
     }
     for (auto &w : workers) w.join();
+    // A failed shard is re-run on a device whose own shard succeeded (units are
+    // independent, so a lost device costs time, not results); only if that fails too is the error returned.
     int failed = 0;
     for (size_t d = 0; d < ndev; d++)
     {
         if (rcs[d] < 0)
         {
-            seamd::set_last_error(errs[d]);
-            return rcs[d];
+            const size_t lo = B * d / ndev, hi = B * (d + 1) / ndev;
+            int rc = rcs[d];
+            for (size_t k = 1; k < ndev && rc < 0; k++)
+            {
+                const size_t h = (d + k) % ndev;
+                if (rcs[h] < 0) continue;
+                se_amd_ctx *ctx = h == 0 ? g_ctx : g_more[h - 1];
+                fprintf(stderr, "se_encrypt_batch: shard %zu (ciphertexts %zu..%zu) failed (%s); re-running it on "
+                                "device slot %zu\n", d, lo, hi, errs[d].c_str(), h);
+                rc = run(ctx, lo, hi - lo);
+            }
+            if (rc < 0)
+            {
+                seamd::set_last_error(errs[d]);
+                return rcs[d];
+            }
+            rcs[d] = rc;
         }
         failed += rcs[d];
     }

@@ -1139,7 +1139,7 @@ def test_c_caller_of_reference_api_reproduces_reference_digest(env, golden, tmp_
     assert kv["fnv1a64"] == golden["digests"]["shapes"][f"{n}x{npr}"][f"api_fnv1a64_{mode}"]
 
 
-@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0", "visible:0,0"])
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0", "visible:0,0", "inject1:0,0,0"])
 def test_c_caller_of_batch_entry(env, tmp_path, devices):
     """examples/batch_encrypt.c: se_encrypt_batch from C with malloc'ed (pageable) buffers; the
     records equal the oracle's per-ciphertext results in the reference's callback order.  With
@@ -1147,7 +1147,8 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
     device; the same device listed repeatedly here, a single-GPU box, still exercises the split; 7
     ciphertexts over 2 or 3 devices = unequal shards).  SE_AMD_DEVICES holds HIP ordinals, i.e. positions
     in the process's visible-device list: under HIP_VISIBLE_DEVICES they are remapped like every HIP
-    index ("visible:" case), and an ordinal outside that list is refused at se_setup."""
+    index ("visible:" case), and an ordinal outside that list is refused at se_setup.  "inject1": shard 1
+    fails (fault injection) and is re-run on the next healthy device slot -- identical records."""
     import subprocess
     from oracle import pyoracle
     from oracle.pyoracle import Oracle
@@ -1155,6 +1156,11 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
     exe = _build_example("batch_encrypt", tmp_path)
     data = _key_dir(env, tmp_path, n, npr, False)
     e = dict(os.environ, SE_AMD_DATA_PATH=str(data))
+    inject = None
+    if devices and devices.startswith("inject"):
+        # a shard whose device "fails" (fault injection) is re-run on a healthy one: same records
+        inject, devices = devices.split(":", 1)
+        e["SE_AMD_INJECT_SHARD_FAILURE"] = inject[len("inject"):]
     if devices and devices.startswith("visible:"):
         e["HIP_VISIBLE_DEVICES"] = "0"
         devices = devices.split(":", 1)[1]
@@ -1163,8 +1169,11 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
         assert bad.returncode != 0 and "device index out of range" in bad.stderr
     if devices:
         e["SE_AMD_DEVICES"] = devices
-    out = subprocess.run([str(exe), str(n), str(npr), str(B)], env=e, check=True, capture_output=True,
-                         text=True, timeout=300).stdout
+    res = subprocess.run([str(exe), str(n), str(npr), str(B)], env=e, check=True, capture_output=True,
+                         text=True, timeout=300)
+    out = res.stdout
+    if inject:
+        assert "shard 1" in res.stderr and "re-running it on device slot 2" in res.stderr
     kv = dict(f.split("=") for f in [l for l in out.splitlines() if l.startswith("failed=")][-1].split())
     o = Oracle(n, npr)
     sk = V.secret_key(n)
