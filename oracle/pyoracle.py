@@ -87,6 +87,8 @@ class Oracle:
             L.seo_index_map.argtypes = [C.c_size_t, C.c_size_t, u16p]
             L.seo_ifft_twiddles.argtypes = [C.c_size_t, C.c_size_t, f64p]
             L.seo_ifft_inpl.argtypes = [f64p, C.c_size_t, C.c_size_t]
+            L.seo_encode_ex.restype = C.c_size_t
+            L.seo_encode_ex.argtypes = [C.POINTER(SeoParams), f32p, C.c_size_t, u16p, i64p]
             L.seo_encode.restype = C.c_int
             L.seo_encode.argtypes = [C.POINTER(SeoParams), f32p, C.c_size_t, u16p, i64p]
             L.seo_cbd_add.argtypes = [i64p, C.c_size_t, u8p, u64p]
@@ -191,6 +193,17 @@ class Oracle:
         ok = self.L.seo_encode(C.byref(self.p), _p(v, f32p), self.n // 2, _p(self.map, u16p),
                                _p(out, i64p))
         return bool(ok), out
+
+    def encode_ex(self, values):
+        """(index of the first coefficient that fails the overflow test or n, coefficients): the first
+        `index` entries are what the reference's in-place loop has converted when it returns false."""
+        v = np.zeros(self.n // 2, dtype=np.float32)
+        vv = np.asarray(values, dtype=np.float32).ravel()
+        v[:vv.size] = vv
+        out = np.zeros(self.n, dtype=np.int64)
+        idx = self.L.seo_encode_ex(C.byref(self.p), _p(v, f32p), self.n // 2, _p(self.map, u16p),
+                                   _p(out, i64p))
+        return int(idx), out
 
     # -- samplers (return (array, next_ctr))
     def cbd_int8(self, seed, ctr=0):
@@ -390,6 +403,8 @@ class Reference:
             L.refh_moduli.argtypes = [C.c_void_p, u32p, u32p, u32p]
             L.refh_index_map.argtypes = [C.c_void_p, u16p]
             L.refh_set_sk.argtypes = [C.c_void_p, u8p]
+            L.refh_encode_ex.restype = C.c_long
+            L.refh_encode_ex.argtypes = [C.c_void_p, f32p, C.c_size_t, i64p]
             L.refh_encode.restype = C.c_int
             L.refh_encode.argtypes = [C.c_void_p, f32p, C.c_size_t, i64p]
             L.refh_shake256.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t]
@@ -483,6 +498,13 @@ class Reference:
         out = np.zeros(self.n, dtype=np.int64)
         ok = self.L.refh_encode(self.h, _p(v, f32p), v.size, _p(out, i64p))
         return bool(ok), out
+
+    def encode_ex(self, values):
+        """(index at which ckks_encode_base returned false or n, the in-place buffer as int64)"""
+        v = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        out = np.zeros(self.n, dtype=np.int64)
+        idx = self.L.refh_encode_ex(self.h, _p(v, f32p), v.size, _p(out, i64p))
+        return int(idx), out
 
     @classmethod
     def shake256(cls, data, outlen):

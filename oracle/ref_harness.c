@@ -152,6 +152,42 @@ int refh_encode(void *vh, const float *v, size_t vlen, int64_t *out)
     return ok ? 1 : 0;
 }
 
+/* ckks_encode_base with the index at which it gave up: the reference reports that index only in the
+ * message it prints before `return false` (ckks_common.c:195-204), so stdout is captured into a
+ * temporary file around the call and the message parsed.  Returns n on success.  out[0 .. index) are the
+ * coefficients the reference's in-place loop had converted by then. */
+long refh_encode_ex(void *vh, const float *v, size_t vlen, int64_t *out)
+{
+    refh *h  = (refh *)vh;
+    size_t n = h->parms.coeff_count;
+    memset(h->ptrs.values, 0, (n / 2) * sizeof(flpt));
+    memcpy(h->ptrs.values, v, vlen * sizeof(flpt));
+    fflush(stdout);
+    FILE *cap = tmpfile();
+    int saved = dup(1);
+    dup2(fileno(cap), 1);
+    bool ok = ckks_encode_base(&h->parms, h->ptrs.values, n / 2, h->ptrs.index_map_ptr,
+                               h->ptrs.ifft_roots, h->ptrs.conj_vals);
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
+    long idx = (long)n;
+    if (!ok)
+    {
+        char line[256];
+        idx = -1;
+        rewind(cap);
+        while (fgets(line, sizeof line, cap))
+        {
+            size_t i;
+            if (sscanf(line, "Error! Value at index %zu", &i) == 1) idx = (long)i;
+        }
+    }
+    fclose(cap);
+    if (out) memcpy(out, h->ptrs.conj_vals_int_ptr, n * sizeof(int64_t));
+    return idx;
+}
+
 void refh_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen)
 {
     shake256(out, outlen, in, inlen);

@@ -326,8 +326,60 @@ static const double *twiddles_for(size_t n, size_t logn)
     return g_tw[slot];
 }
 
+/* The reference multiplies `double complex` values with the C operator (fft.c:139, :205).  gcc (default
+ * -fcx-... settings of the Release build: no -ffast-math) expands that into the Annex-G form
+ *     x = ac - bd,  y = ad + bc          (one rounding per operation)
+ * and, when x or y comes out NaN, calls libgcc's __muldc3, which recomputes x and y the same way and -- only
+ * when BOTH are NaN -- "recovers infinities" (C99 G.5.1): an infinite factor is boxed to (+-1 | +-0), NaNs in the
+ * other factor become signed zeros, and the product is INFINITY * (ac - bd), INFINITY * (ad + bc).  On finite
+ * data none of this triggers; on non-finite plaintext values (NaN, +-Inf floats are legal inputs of
+ * ckks_encode_base) it decides which coefficients are NaN (accepted, converted to INT64_MIN by x86's
+ * cvttsd2si) and which are infinite (the overflow `return false` of ckks_common.c:195-204).
+ * Restated from the published libgcc algorithm (libgcc2.c, __mulMODE3); pinned against the compiled
+ * reference by tests/test_oracle.py::test_encode_nonfinite_matches_reference. */
+static inline void seo_cmul(double a, double b, double c, double d, double *xo, double *yo)
+{
+    double ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    double x = ac - bd, y = ad + bc;
+    if (isnan(x) && isnan(y))
+    {
+        int recalc = 0;
+        if (isinf(a) || isinf(b))
+        {
+            a = copysign(isinf(a) ? 1.0 : 0.0, a);
+            b = copysign(isinf(b) ? 1.0 : 0.0, b);
+            if (isnan(c)) c = copysign(0.0, c);
+            if (isnan(d)) d = copysign(0.0, d);
+            recalc = 1;
+        }
+        if (isinf(c) || isinf(d))
+        {
+            c = copysign(isinf(c) ? 1.0 : 0.0, c);
+            d = copysign(isinf(d) ? 1.0 : 0.0, d);
+            if (isnan(a)) a = copysign(0.0, a);
+            if (isnan(b)) b = copysign(0.0, b);
+            recalc = 1;
+        }
+        if (!recalc && (isinf(ac) || isinf(bd) || isinf(ad) || isinf(bc)))
+        {
+            if (isnan(a)) a = copysign(0.0, a);
+            if (isnan(b)) b = copysign(0.0, b);
+            if (isnan(c)) c = copysign(0.0, c);
+            if (isnan(d)) d = copysign(0.0, d);
+            recalc = 1;
+        }
+        if (recalc)
+        {
+            x = INFINITY * (a * c - b * d);
+            y = INFINITY * (a * d + b * c);
+        }
+    }
+    *xo = x;
+    *yo = y;
+}
+
 /* fft.c:69-144: rounds tt = 1,2,..,n/2; (u,v) -> (u+v, (u-v)*s); no 1/n.
- * Complex product in C99 Annex-G operand order: (ac - bd, ad + bc), one rounding per op. */
+ * Complex product in C99 Annex-G operand order: (ac - bd, ad + bc), one rounding per op (seo_cmul). */
 void seo_ifft_inpl(double *x, size_t n, size_t logn)
 {
     const double *w = twiddles_for(n, logn);
@@ -344,16 +396,18 @@ void seo_ifft_inpl(double *x, size_t n, size_t logn)
                 double a = ur - vr, b = ui - vi;
                 x[2 * k]            = ur + vr;
                 x[2 * k + 1]        = ui + vi;
-                x[2 * (k + tt)]     = a * c - b * d;
-                x[2 * (k + tt) + 1] = a * d + b * c;
+                seo_cmul(a, b, c, d, &x[2 * (k + tt)], &x[2 * (k + tt) + 1]);
             }
         }
     }
 }
 
-/* ckks_common.c:105-215 */
-int seo_encode(const seo_params *p, const float *values, size_t values_len, const uint16_t *map,
-               int64_t *out)
+/* ckks_common.c:105-215.  Returns the index of the first coefficient that fails the overflow test
+ * (:195-204; the reference returns false there, leaving out[0 .. index) converted), or n when none does.
+ * A NaN coefficient does NOT fail (fabs(NaN) > 2^63 is false): the reference stores (int64_t)NaN, which
+ * its x86-64 build evaluates with cvttsd2si to the "integer indefinite" INT64_MIN; so does +-2^63. */
+size_t seo_encode_ex(const seo_params *p, const float *values, size_t values_len, const uint16_t *map,
+                     int64_t *out)
 {
     size_t n  = p->n;
     double *x = (double *)calloc(2 * n, sizeof(double));
@@ -367,19 +421,22 @@ int seo_encode(const seo_params *p, const float *values, size_t values_len, cons
     }
     seo_ifft_inpl(x, n, p->logn);
     double n_inv = p->scale / (double)n; /* :183 */
-    int ok       = 1;
-    for (size_t i = 0; i < n; i++)
+    size_t i;
+    for (i = 0; i < n; i++)
     {
         double coeff = round(x[2 * i] * n_inv);
-        if (fabs(coeff) > 9223372036854775808.0)
-        { /* :195 MAX_INT_64_DOUBLE == 2^63 after conversion */
-            ok = 0;
-            break;
-        }
-        out[i] = (int64_t)coeff;
+        if (fabs(coeff) > 9223372036854775808.0) break; /* :195 MAX_INT_64_DOUBLE == 2^63 after conversion */
+        /* (int64_t)coeff is undefined in C for NaN and 2^63; the reference's build yields INT64_MIN */
+        out[i] = (coeff >= -9223372036854775808.0 && coeff < 9223372036854775808.0) ? (int64_t)coeff : INT64_MIN;
     }
     free(x);
-    return ok;
+    return i;
+}
+
+int seo_encode(const seo_params *p, const float *values, size_t values_len, const uint16_t *map,
+               int64_t *out)
+{
+    return seo_encode_ex(p, values, values_len, map, out) == p->n;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -729,7 +786,8 @@ void seo_fft_inpl(double *x, size_t n, size_t logn)
             {
                 double ur = x[2 * k], ui = x[2 * k + 1];
                 double a = x[2 * (k + tt)], b = x[2 * (k + tt) + 1];
-                double vr = a * c - b * d, vi = a * d + b * c;
+                double vr, vi;
+                seo_cmul(a, b, c, d, &vr, &vi);
                 x[2 * k]            = ur + vr;
                 x[2 * k + 1]        = ui + vi;
                 x[2 * (k + tt)]     = ur - vr;

@@ -63,6 +63,8 @@ void seo_index_map(size_t n, size_t logn, uint16_t *map /*[n]*/);
 void seo_ifft_twiddles(size_t n, size_t logn, double *w_re_im /*[2n]*/);
 void seo_ifft_inpl(double *x_re_im /*[2n] interleaved*/, size_t n, size_t logn);
 /* returns 1 on success, 0 if a coefficient overflows int64 (reference returns false) */
+size_t seo_encode_ex(const seo_params *p, const float *values, size_t values_len, const uint16_t *map,
+                     int64_t *out /*[n]*/);   /* first failing index, n when none */
 int seo_encode(const seo_params *p, const float *values, size_t values_len, const uint16_t *map,
                int64_t *out /*[n]*/);
 

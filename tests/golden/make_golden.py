@@ -126,6 +126,21 @@ def main():
         big = np.full(n // 2, 3.0e38, dtype=np.float32)
         ok_big, _ = R.encode(big)
         enc["overflow_3e38_ok"] = bool(ok_big)
+        # non-finite / edge-magnitude values: where ckks_encode_base gives up (n: nowhere) and what its
+        # in-place loop had converted by then; accepted plaintexts (NaN -> INT64_MIN) also end to end
+        nf = []
+        for c in range(V.NONFINITE_CASES):
+            vals = V.nonfinite_values(c, n)
+            idx, m = R.encode_ex(vals)
+            assert idx >= 0
+            ent = {"fail_index": idx, "prefix_sha256": V.sha256_hex(m[:idx]),
+                   "int64_min_count": int((m[:idx] == -2 ** 63).sum())}
+            if idx == n:
+                r = R.encrypt_sym(vals, SEED_A, SEED_B)
+                assert r["ok"]
+                ent["c0_sha256"], ent["pte_sha256"] = V.sha256_hex(r["c0"]), V.sha256_hex(r["pte"])
+            nf.append(ent)
+        enc["nonfinite"] = nf
         d["encode"] = enc
 
         # G4 samplers

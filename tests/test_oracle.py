@@ -118,6 +118,22 @@ def test_oracle_vs_golden(golden, shape):
     ok, _ = o.encode(np.full(n // 2, 3.0e38, dtype=np.float32))
     assert ok == d["encode"]["overflow_3e38_ok"] and not ok
 
+    # non-finite / edge-magnitude values (NaN -> INT64_MIN, Inf -> return false at a definite index)
+    sk = V.secret_key(n)
+    kinds = set()
+    for c, g in enumerate(d["encode"]["nonfinite"]):
+        vals = V.nonfinite_values(c, n)
+        idx, m = o.encode_ex(vals)
+        assert idx == g["fail_index"] and V.sha256_hex(m[:idx]) == g["prefix_sha256"], c
+        assert int((m[:idx] == -2 ** 63).sum()) == g["int64_min_count"]
+        kinds.add((idx == n, g["int64_min_count"] > 0))
+        if idx == n:
+            r = o.encrypt_sym(vals, SEED_A, SEED_B, sk)
+            assert r["ok"] and V.sha256_hex(r["c0"]) == g["c0_sha256"], c
+            assert V.sha256_hex(r["pte"]) == g["pte_sha256"], c
+    assert {(True, True), (True, False), (False, False)} <= kinds   # accepted NaN, ordinary, rejected
+    assert any(0 < g["fail_index"] < n for g in d["encode"]["nonfinite"])   # rejected behind a prefix
+
     ctr = 0
     for j in range(npr):
         g = d["samplers"][f"uniform_p{j}"]
@@ -305,6 +321,38 @@ def test_oracle_vs_live_reference_random(shape):
             w = int(rng.integers(0, 2 ** 32))
             assert o.barrett32(w, j) == R.barrett32(w, j) == w % o.q[j]
     R.close()
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("shape", [(1024, 1), (4096, 3), (16384, 6)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_encode_nonfinite_matches_reference(shape):
+    """NaN / Inf / FLT_MAX / subnormal / -0.0 plaintext values, fresh random placements: the index at which
+    the compiled reference's ckks_encode_base returns false (n: it does not) and everything its in-place
+    loop converted before that equal the restatement's -- including the Annex-G infinity recovery of the
+    complex product (seo_cmul), without which about 1 case in 300 differs."""
+    n, npr = shape
+    o, r = Oracle(n, npr), pyoracle.Reference(n, npr)
+    rng = np.random.default_rng(n + 77)
+    specials = np.array([np.inf, -np.inf, np.nan, 3.4028235e38, -3.4028235e38, 1e-45, -0.0, 0.0, 1e-39],
+                        dtype=np.float32)
+    seen_fail = seen_nan = 0
+    for trial in range(120 if n < 16384 else 30):
+        v = (rng.random(n // 2, dtype=np.float32) * 50 - 25).astype(np.float32)
+        pool = specials[rng.choice(len(specials), size=int(rng.integers(1, len(specials) + 1)), replace=False)]
+        k = int(rng.integers(1, 6))
+        v[rng.choice(n // 2, size=k, replace=False)] = rng.choice(pool, size=k)
+        if trial % 7 == 0:
+            v[:] = rng.choice(pool, size=n // 2)
+        if trial % 7 == 1:
+            v[rng.random(n // 2) < 0.5] = rng.choice(pool)
+        ia, a = o.encode_ex(v)
+        ib, b = r.encode_ex(v)
+        assert ia == ib and np.array_equal(a[:ia], b[:ib]), (trial, ia, ib)
+        seen_fail += ib < n
+        seen_nan += ib == n and bool((b == -2 ** 63).any())
+    assert seen_fail and seen_nan
+    r.close()
 
 
 def test_batched_driver_matches_single():

@@ -108,5 +108,57 @@ def pattern_values(testnum, n, seed=7):
     return v
 
 
+# Non-finite / edge-magnitude plaintext values.  The reference accepts them: a NaN coefficient passes
+# the overflow test (fabs(NaN) > 2^63 is false, ckks_common.c:195) and is stored as (int64_t)NaN =
+# INT64_MIN by the x86-64 build; an infinite coefficient is the `return false`; which coefficients
+# are NaN and which infinite is decided by the Annex-G complex product of the IFFT (oracle/se_oracle.c,
+# seo_cmul).  Cases 0-8 are fixed; 9-15 are seeded mixes of specials among ordinary values; 16-19 place
+# a few +Inf and -Inf so that the FIRST coefficients come out NaN (accepted) and a later one infinite: the
+# reference returns false at an index > 0 with a converted prefix behind it.
+NONFINITE_CASES = 20
+_SPECIALS = np.array([np.inf, -np.inf, np.nan, 3.4028235e38, -3.4028235e38, 1e-45, -1e-45, -0.0, 1e-39],
+                     dtype=np.float32)
+
+
+def nonfinite_values(case, n, seed=99):
+    vlen = n // 2
+    rng = np.random.default_rng(seed * 1000 + case * 17 + n)
+    v = (rng.integers(0, 256, vlen).astype(np.float64) / -10.0).astype(np.float32)
+    if case == 0:
+        v[0] = np.nan
+    elif case == 1:
+        v[:] = np.nan
+    elif case == 2:
+        v[5] = np.inf
+    elif case == 3:
+        v[vlen - 1] = -np.inf
+    elif case == 4:
+        v[rng.random(vlen) < 0.25] = np.inf
+        v[rng.random(vlen) < 0.25] = -np.inf
+    elif case == 5:
+        v[:] = -0.0
+    elif case == 6:
+        v[0::3], v[1::3], v[2::3] = np.float32(1e-45), np.float32(-1e-45), np.float32(1e-39)
+    elif case == 7:
+        v[:] = np.float32(3.4028235e38)
+    elif case == 8:
+        v[:] = 0
+        v[vlen // 2] = np.float32(-3.4028235e38)
+    elif case >= 16:
+        if case < 18:
+            v[:] = 0
+        k = int(rng.integers(2, 5))
+        pos = rng.choice(vlen, size=k, replace=False)
+        v[pos] = np.where(rng.random(k) < 0.5, np.float32(np.inf), np.float32(-np.inf))
+        v[pos[0]], v[pos[1]] = np.float32(np.inf), np.float32(-np.inf)
+    else:
+        k = int(rng.integers(1, 7))
+        pool = _SPECIALS[rng.choice(len(_SPECIALS), size=int(rng.integers(1, 5)), replace=False)]
+        v[rng.choice(vlen, size=k, replace=False)] = rng.choice(pool, size=k)
+        if case % 3 == 0:
+            v[rng.random(vlen) < 0.5] = rng.choice(pool)
+    return v
+
+
 def sha256_hex(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
