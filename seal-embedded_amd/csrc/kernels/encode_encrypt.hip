@@ -140,11 +140,21 @@ __device__ __forceinline__ int thread_index()
         return threadIdx.x;
 }
 
-template <int LOGN, typename MT>
+// Workgroup-wide outcome of the encoder (one OR-reduction over the workgroup, returned in `wg`):
+constexpr int kWgOverflow  = 1;   // a coefficient fails the reference's overflow test (ckks_common.c:195)
+constexpr int kWgNotSmall  = 2;   // some |m| >= 2 q_min - 64 (or a non-finite value in the fast form)
+constexpr int kWgNonfinite = 4;   // int64 form: the plaintext holds a NaN or an infinite value
+// BRANCH_EXACT (int64 form only): a plaintext with a NaN / infinite value takes the EXACT transform
+// (transform.cuh, cmul_annexg), chosen by a workgroup-uniform branch -- the general kernels.  Without it the
+// int64 form (k_encode_rns, whose register budget the second transform would cost 30 VGPRs) only REPORTS
+// kWgNonfinite: its outputs are then meaningless, no status is written and the caller hands the plaintext
+// to its general kernel.
+template <int LOGN, typename MT, bool BRANCH_EXACT>
 __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTables &T,
                                                  const float *values, uint8_t *status, size_t b,
-                                                 unsigned char *smem, MT (&m)[16], bool &small)
+                                                 unsigned char *smem, MT (&m)[16], bool &small, int &wg)
 {
+    static_assert(sizeof(MT) == 8 || !BRANCH_EXACT, "the fast form never sees a non-finite plaintext through");
     const int t = thread_index<sizeof(MT) == 8>();
     using G          = XformGeom<LOGN>;
     constexpr int N  = G::N;
@@ -156,6 +166,16 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     // onto [0,n), so slot k is filled from values[inv_map[k] mod n/2].  The staging array is laid out
     // through sv_slot() (se_types.h) so that the gather is bank-conflict-free; gather_map holds the
     // LDS position directly.
+    //
+    // NaN and infinite values are legal inputs of the reference (a NaN coefficient passes its overflow
+    // test and is stored as INT64_MIN, ckks_common.c:195-206; an infinite one is the `return false`), and
+    // they are the ONLY way a non-finite number enters the transform (|value| <= FLT_MAX keeps every
+    // intermediate below 2^143).  Each thread folds the values it stages into v * 0 + acc, which is NaN
+    // exactly when one of them is NaN or infinite (four v_pk_fma_f32): the fast form declines such a
+    // plaintext (`small` comes back false), the general form takes the EXACT transform (transform.cuh,
+    // cmul_annexg) for it.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f nfacc = {0.0f, 0.0f};
     {
         const float4 *src = reinterpret_cast<const float4 *>(values + b * (N / 2));
         static_assert((N / 8) % TH == 0, "every thread stages the same number of float4 pieces");
@@ -164,13 +184,21 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
         {
             const int i    = t + k * TH;
             const float4 v = src[i];
+            nfacc          = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{0.0f, 0.0f}, nfacc);
+            nfacc          = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{0.0f, 0.0f}, nfacc);
             sv[sv_slot(4u * i, LOGN)]      = v.x;
             sv[sv_slot(4u * i + 1u, LOGN)] = v.y;
             sv[sv_slot(4u * i + 2u, LOGN)] = v.z;
             sv[sv_slot(4u * i + 3u, LOGN)] = v.w;
         }
     }
-    __syncthreads();
+    const float nfsum    = nfacc.x + nfacc.y;
+    const bool nonfinite = nfsum != nfsum;   // this thread staged a NaN or an infinity
+    bool wg_nonfinite    = false;            // workgroup-uniform
+    if constexpr (BRANCH_EXACT)
+        wg_nonfinite = __syncthreads_or(nonfinite) != 0;
+    else
+        __syncthreads();
     double re[16], im[16];
     {
         // [2][n/16] uint4: half h of thread t's 16 entries at row h -- a wave load covers 1 KiB contiguous
@@ -188,11 +216,22 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     __syncthreads();
 
     // inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183)
+    auto plain_ifft = [&]() {
 #ifdef SEAMD_NO_REAL_PASS0
-    ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
+        ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
 #else
-    ifft_tiles<LOGN, true>(re, im, T.ifft_w, plane, t);  // real input: short butterflies in pass 0
+        ifft_tiles<LOGN, true>(re, im, T.ifft_w, plane, t);  // real input: short butterflies in pass 0
 #endif
+    };
+    if constexpr (BRANCH_EXACT)
+    {
+        if (wg_nonfinite)
+            ifft_tiles<LOGN, false, true>(re, im, T.ifft_w, plane, t);
+        else
+            plain_ifft();
+    }
+    else
+        plain_ifft();
 
     // round to int64, overflow check (ckks_common.c:183-206).  The largest magnitude of the thread
     // serves both the overflow test and the wave-uniform "small" flag: when every coefficient of
@@ -206,37 +245,45 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
         re[e] = round(__dmul_rn(re[e], P.n_inv));
         amax  = fmax(amax, fabs(re[e]));
     }
+    // fmax() skips NaNs: a NaN coefficient is not an overflow for the reference (ckks_common.c:195)
     const int ok = !(amax > 9223372036854775808.0);
-    small        = __all(amax < P.small_bound);
     if constexpr (sizeof(MT) == 4)
     {
+        small = __all(amax < P.small_bound && !nonfinite);
 #pragma unroll
         for (int e = 0; e < 16; e++) m[e] = (int32_t)re[e];
     }
-    else if (small)
-    {
-#pragma unroll
-        for (int e = 0; e < 16; e++) m[e] = (int64_t)(int32_t)re[e];
-    }
     else
     {
-        // |coefficient| == 2^63 passes the reference's check (it rejects only > 2^63,
-        // ckks_common.c:195) and its x86-64 conversion yields INT64_MIN for +2^63 as well
+        small = __all(amax < P.small_bound && !nonfinite) && !wg_nonfinite;
+        if (small)
+        {
 #pragma unroll
-        for (int e = 0; e < 16; e++)
-            m[e] = (re[e] == 9223372036854775808.0) ? INT64_MIN : (int64_t)re[e];
+            for (int e = 0; e < 16; e++) m[e] = (int64_t)(int32_t)re[e];
+        }
+        else
+        {
+            // the reference's x86-64 build converts with cvttsd2si: NaN and +2^63 (which passes its check: it
+            // rejects only > 2^63) come out as the "integer indefinite" INT64_MIN; the device conversion
+            // saturates and maps NaN to 0
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                m[e] = (fabs(re[e]) < 9223372036854775808.0) ? (int64_t)re[e] : INT64_MIN;
+        }
     }
+    // ONE reduction over the workgroup carries everything the callers need
+    wg = __ockl_wgred_or_i32((ok ? 0 : kWgOverflow) | (small ? 0 : kWgNotSmall) | (nonfinite ? kWgNonfinite : 0));
     if constexpr (sizeof(MT) == 4)
     {
         // fast form: `small` for the whole workgroup (it implies "no overflow"); a plaintext that is not
         // small gets its status from the general kernel
-        small = __syncthreads_and(small) != 0;
+        small = !(wg & kWgNotSmall);
         if (status && t == 0 && small) status[b] = 1;
     }
     else
     {
-        const int all_ok = __syncthreads_and(ok);
-        if (status && t == 0) status[b] = (uint8_t)all_ok;
+        const bool declined = !BRANCH_EXACT && (wg & kWgNonfinite);
+        if (status && t == 0 && !declined) status[b] = (wg & kWgOverflow) ? 0 : 1;
     }
 }
 
@@ -273,7 +320,8 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     using MT = typename std::conditional<GENERAL, int64_t, int32_t>::type;
     MT m[16];
     bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
-    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
+    int wg;
+    encode_plaintext<LOGN, MT, GENERAL>(P, T, A.values, A.status, b, smem, m, small, wg);
     if constexpr (!GENERAL)
     {
         if (!small)   // workgroup-uniform in the fast form (encode_plaintext)
@@ -493,21 +541,33 @@ void k_encode_encrypt_general(DevParams P, DevTables T, EncArgs A)
 //   k_ntt_fuse   : prime j of every ciphertext: load residues from c0_j, forward NTT, then
 //                  c0_j = NTT(m+e) - s_hat . a_j  with a_j read from c1_j (ckks_sym.c:273-300).
 // ------------------------------------------------------------------------------------------
-template <int LOGN, bool ADD_ERR>
-__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevParams P, DevTables T,
-                                                                      EncArgs A)
+// Like the fused kernel it comes as a fast / general pair: the fast launch declines a plaintext that holds
+// a NaN or an infinite value (it appends the index to A.general and writes nothing); k_encode_rns_general
+// walks that list with the EXACT transform.  Keeping the second transform out of the fast kernel is what
+// keeps its registers (120 VGPRs, 104 at n = 16384; with a branch to the exact form inside: 150, and 128 +
+// 92 B of spills at n = 16384).
+template <int LOGN, bool ADD_ERR, bool GENERAL>
+__device__ __forceinline__ void encode_rns_one(const DevParams &P, const DevTables &T, const EncArgs &A,
+                                               const size_t b, unsigned char *smem)
 {
     using G            = XformGeom<LOGN>;
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t    = threadIdx.x;
-    const size_t b = blockIdx.x;
+    const int t    = thread_index<GENERAL>();
     const int np   = P.nprimes;
 
     int64_t m[16];
     bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
-    encode_plaintext<LOGN>(P, T, A.values, A.status, b, smem, m, small);
+    int wg;
+    encode_plaintext<LOGN, int64_t, GENERAL>(P, T, A.values, A.status, b, smem, m, small, wg);
+    if constexpr (!GENERAL)
+    {
+        if (wg & kWgNonfinite)
+        {
+            if (t == 0) A.general[1 + atomicAdd(A.general, 1u)] = (uint32_t)b;
+            return;
+        }
+    }
     if constexpr (ADD_ERR)
     {
 #pragma unroll
@@ -524,7 +584,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
     // this kernel is HBM-bound (6 x 64 KiB of residues per plaintext against 48 KiB of inputs).
     if (A.compact)
     {
-        const bool compact = __syncthreads_and(small) != 0;
+        const bool compact = !(wg & kWgNotSmall);
         if (t == 0) A.compact[b] = compact ? 1 : 0;
         if (compact)
         {
@@ -541,6 +601,27 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevPara
         uint32_t *dst = A.c0 + (b * np + j) * N;
 #pragma unroll
         for (int e = 0; e < 16; e++) dst[(e << CTOP) + t] = x[e];
+    }
+}
+
+template <int LOGN, bool ADD_ERR>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns(DevParams P, DevTables T,
+                                                                      EncArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    encode_rns_one<LOGN, ADD_ERR, false>(P, T, A, blockIdx.x, smem);
+}
+
+template <int LOGN, bool ADD_ERR>
+__global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_encode_rns_general(DevParams P, DevTables T,
+                                                                              EncArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t count = A.general[0];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x)
+    {
+        encode_rns_one<LOGN, ADD_ERR, true>(P, T, A, A.general[1 + i], smem);
+        __syncthreads();
     }
 }
 
@@ -856,26 +937,34 @@ hipError_t launch_encode_encrypt(const DevParams &P, const DevTables &T, const E
     }
 }
 
+template <int LOGN, bool ADD_ERR>
+static hipError_t launch_enc_rns_e(const DevParams &P, const DevTables &T, const EncArgs &A, size_t B,
+                                   hipStream_t st)
+{
+    using G      = XformGeom<LOGN>;
+    size_t shmem = (size_t)G::SLOTS * sizeof(double);
+    if (!A.general) return hipErrorInvalidValue;   // the context's list of declined plaintexts
+    hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    (void)hipFuncSetAttribute((const void *)k_encode_rns<LOGN, ADD_ERR>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((k_encode_rns<LOGN, ADD_ERR>), dim3((unsigned)B), dim3(G::THREADS), shmem, st, P, T, A);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // plaintexts with NaN / infinite values (normally none: the workgroups read a zero count and leave)
+    const unsigned cus  = P.num_cus ? P.num_cus : 256u;
+    const unsigned grid = (unsigned)std::min<size_t>(B, (size_t)cus);
+    (void)hipFuncSetAttribute((const void *)k_encode_rns_general<LOGN, ADD_ERR>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((k_encode_rns_general<LOGN, ADD_ERR>), dim3(grid), dim3(G::THREADS), shmem, st, P, T, A);
+    return hipGetLastError();
+}
+
 template <int LOGN>
 static hipError_t launch_enc_rns(const DevParams &P, const DevTables &T, const EncArgs &A, bool add_err,
                                  size_t B, hipStream_t st)
 {
-    using G      = XformGeom<LOGN>;
-    size_t shmem = (size_t)G::SLOTS * sizeof(double);
-    dim3 grid((unsigned)B), block(G::THREADS);
-    if (add_err)
-    {
-        (void)hipFuncSetAttribute((const void *)k_encode_rns<LOGN, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL((k_encode_rns<LOGN, true>), grid, block, shmem, st, P, T, A);
-    }
-    else
-    {
-        (void)hipFuncSetAttribute((const void *)k_encode_rns<LOGN, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL((k_encode_rns<LOGN, false>), grid, block, shmem, st, P, T, A);
-    }
-    return hipGetLastError();
+    return add_err ? launch_enc_rns_e<LOGN, true>(P, T, A, B, st) : launch_enc_rns_e<LOGN, false>(P, T, A, B, st);
 }
 
 hipError_t launch_encode_rns(const DevParams &P, const DevTables &T, const EncArgs &A, bool add_err,

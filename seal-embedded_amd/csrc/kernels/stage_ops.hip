@@ -89,7 +89,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_fft_polys(DevParam
             const double2 v = *reinterpret_cast<const double2 *>(in + 2 * ((e << CTOP) + t));
             re[e] = v.x, im[e] = v.y;
         }
-        fft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
+        fft_tiles<LOGN, true>(re, im, T.ifft_w, plane, t);   // EXACT: the caller may pass NaN / Inf
         double *out = A.out_cplx + b * 2 * N;
 #pragma unroll
         for (int e = 0; e < 16; e++)
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_fft_polys(DevParam
         const double2 v = *reinterpret_cast<const double2 *>(in + 2 * (16 * t + e));
         re[e] = v.x, im[e] = v.y;
     }
-    ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
+    ifft_tiles<LOGN, false, true>(re, im, T.ifft_w, plane, t);   // EXACT product (transform.cuh, cmul_annexg)
     if (A.out_cplx)
     {
         double *out = A.out_cplx + b * 2 * N;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS) void k_fft_polys(DevParam
     {
         const double c = round(__dmul_rn(re[e], P.n_inv));
         if (fabs(c) > 9223372036854775808.0) first_bad = (uint32_t)((e << CTOP) + t);
-        // (int64_t)(2^63) is the x86-64 "integer indefinite" value in the reference's build
-        A.out_int[b * N + (e << CTOP) + t] = (c == 9223372036854775808.0) ? INT64_MIN : (int64_t)c;
+        // (int64_t) of NaN and of 2^63 is the x86-64 "integer indefinite" value in the reference's build
+        A.out_int[b * N + (e << CTOP) + t] = (fabs(c) < 9223372036854775808.0) ? (int64_t)c : INT64_MIN;
     }
     if (first_bad != 0xFFFFFFFFu) atomicMin(A.fail_idx + b, first_bad);
 }

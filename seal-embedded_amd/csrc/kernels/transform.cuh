@@ -149,9 +149,80 @@ __device__ __forceinline__ int quad_index(int t, int i)
 }
 
 // ------------------------------------------------------------------------------------------
+// Complex product (a + ib)(c + id) as the reference's build evaluates the C operator `*` on
+// `double complex` (fft.c:139, :205): Annex-G form x = ac - bd, y = ad + bc, one rounding per operation.
+// EXACT additionally reproduces what gcc's expansion does when the result is NaN + iNaN: libgcc's __muldc3
+// "recovers infinities" (C99 G.5.1) -- an infinite factor is boxed to (+-1 | +-0), NaNs of the other factor
+// become signed zeros, and the product is INFINITY * (ac - bd), INFINITY * (ad + bc).  That never triggers
+// on finite data (the hot kernels use EXACT = false and only ever see finite values: encode_plaintext hands
+// a plaintext with a NaN / infinite value to the EXACT path), but it decides which coefficients of such a
+// plaintext are NaN (accepted by ckks_common.c:195, stored as INT64_MIN) and which are infinite (`return
+// false`).  Restated from the published libgcc algorithm (libgcc2.c, __mulMODE3); the GPU tests pin it
+// against outputs of the compiled reference.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dev_copysign(double mag, double sgn)
+{
+    return __longlong_as_double((__double_as_longlong(mag) & 0x7FFFFFFFFFFFFFFFll) |
+                                (__double_as_longlong(sgn) & (long long)0x8000000000000000ull));
+}
+__device__ __forceinline__ bool dev_isinf(double v)
+{
+    return (__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFll) == 0x7FF0000000000000ll;
+}
+__device__ __forceinline__ bool dev_isnan(double v) { return v != v; }
+
+__device__ inline void cmul_recover(double a, double b, double c, double d, double ac, double bd, double ad,
+                                    double bc, double &x, double &y)
+{
+    bool recalc = false;
+    if (dev_isinf(a) || dev_isinf(b))
+    {
+        a = dev_copysign(dev_isinf(a) ? 1.0 : 0.0, a);
+        b = dev_copysign(dev_isinf(b) ? 1.0 : 0.0, b);
+        if (dev_isnan(c)) c = dev_copysign(0.0, c);
+        if (dev_isnan(d)) d = dev_copysign(0.0, d);
+        recalc = true;
+    }
+    if (dev_isinf(c) || dev_isinf(d))
+    {
+        c = dev_copysign(dev_isinf(c) ? 1.0 : 0.0, c);
+        d = dev_copysign(dev_isinf(d) ? 1.0 : 0.0, d);
+        if (dev_isnan(a)) a = dev_copysign(0.0, a);
+        if (dev_isnan(b)) b = dev_copysign(0.0, b);
+        recalc = true;
+    }
+    if (!recalc && (dev_isinf(ac) || dev_isinf(bd) || dev_isinf(ad) || dev_isinf(bc)))
+    {
+        if (dev_isnan(a)) a = dev_copysign(0.0, a);
+        if (dev_isnan(b)) b = dev_copysign(0.0, b);
+        if (dev_isnan(c)) c = dev_copysign(0.0, c);
+        if (dev_isnan(d)) d = dev_copysign(0.0, d);
+        recalc = true;
+    }
+    if (recalc)
+    {
+        const double inf = __longlong_as_double(0x7FF0000000000000ll);
+        x = __dmul_rn(inf, __dsub_rn(__dmul_rn(a, c), __dmul_rn(b, d)));
+        y = __dmul_rn(inf, __dadd_rn(__dmul_rn(a, d), __dmul_rn(b, c)));
+    }
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void cmul_annexg(double a, double b, double c, double d, double &x, double &y)
+{
+    const double ac = __dmul_rn(a, c), bd = __dmul_rn(b, d), ad = __dmul_rn(a, d), bc = __dmul_rn(b, c);
+    x = __dsub_rn(ac, bd);
+    y = __dadd_rn(ad, bc);
+    if constexpr (EXACT)
+    {
+        if (dev_isnan(x) && dev_isnan(y)) cmul_recover(a, b, c, d, ac, bd, ad, bc, x, y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // IFFT pass: stages for local bits [B_LO, B_HI) of a tile at window C, ascending.
 // ------------------------------------------------------------------------------------------
-template <int LOGN, int C, int B_LO, int B_HI>
+template <int LOGN, int C, int B_LO, int B_HI, bool EXACT = false>
 __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
                                           const double *__restrict__ W, int t)
 {
@@ -175,8 +246,7 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
                 double ai = __dsub_rn(im[e0], im[e1]);
                 re[e0]    = __dadd_rn(re[e0], re[e1]);
                 im[e0]    = __dadd_rn(im[e0], im[e1]);
-                re[e1]    = __dsub_rn(__dmul_rn(ar, w.x), __dmul_rn(ai, w.y));
-                im[e1]    = __dadd_rn(__dmul_rn(ar, w.y), __dmul_rn(ai, w.x));
+                cmul_annexg<EXACT>(ar, ai, w.x, w.y, re[e1], im[e1]);
             });
         });
     });
@@ -232,34 +302,36 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
 // Whole IFFT: input in tile layout 0 (thread t holds points 16t..16t+15), output in tile layout
 // LOGN-4 (thread t holds points t + (n/16)*e).  `plane` = LDS scratch of XformGeom::SLOTS doubles.
 // REAL_IN: the imaginary parts of the input are all +0 (im[] need not be initialised except im[0]).
-template <int LOGN, bool REAL_IN = false>
+// EXACT: the Annex-G product with libgcc's infinity recovery (cmul_annexg) -- for plaintexts that hold NaN or
+// infinite values and for the stand-alone operators, whose caller may pass anything; im[] fully initialised.
+template <int LOGN, bool REAL_IN = false, bool EXACT = false>
 __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
                                            const double *__restrict__ W, double *plane, int t)
 {
     using G = XformGeom<LOGN>;
-    if constexpr (REAL_IN)
+    if constexpr (REAL_IN && !EXACT)
         ifft_pass0_real<LOGN>(re, im, W, t);
     else
-        ifft_pass<LOGN, 0, 0, 4>(re, im, W, t);
+        ifft_pass<LOGN, 0, 0, 4, EXACT>(re, im, W, t);
     redeal<0, 4>(re, plane, t);
     redeal<0, 4>(im, plane, t);
-    ifft_pass<LOGN, 4, 0, 4>(re, im, W, t);
+    ifft_pass<LOGN, 4, 0, 4, EXACT>(re, im, W, t);
     if constexpr (LOGN <= 12)
     {
         constexpr int C2 = G::ifft_c(2);  // 6, 7 or 8
         redeal<4, C2>(re, plane, t);
         redeal<4, C2>(im, plane, t);
-        ifft_pass<LOGN, C2, 8 - C2, 4>(re, im, W, t);
+        ifft_pass<LOGN, C2, 8 - C2, 4, EXACT>(re, im, W, t);
     }
     else
     {
         redeal<4, 8>(re, plane, t);
         redeal<4, 8>(im, plane, t);
-        ifft_pass<LOGN, 8, 0, 4>(re, im, W, t);
+        ifft_pass<LOGN, 8, 0, 4, EXACT>(re, im, W, t);
         constexpr int C3 = G::ifft_c(3);  // 9 or 10
         redeal<8, C3>(re, plane, t);
         redeal<8, C3>(im, plane, t);
-        ifft_pass<LOGN, C3, 12 - C3, 4>(re, im, W, t);
+        ifft_pass<LOGN, C3, 12 - C3, 4, EXACT>(re, im, W, t);
     }
 }
 
@@ -459,7 +531,7 @@ __device__ __forceinline__ void intt_tiles(uint32_t (&x)[16], const uint32_t *__
 
 // Forward FFT pass (fft.c:146-213): DIT stages for local bits [B_LO, B_HI), descending;
 // (u, v) -> (u + v*s, u - v*s) with s = conj(W[h + j]) = (W.re, -W.im), product in Annex-G order.
-template <int LOGN, int C, int B_LO, int B_HI>
+template <int LOGN, int C, int B_LO, int B_HI, bool EXACT = false>
 __device__ __forceinline__ void fft_pass(double (&re)[16], double (&im)[16],
                                          const double *__restrict__ W, int t)
 {
@@ -477,8 +549,8 @@ __device__ __forceinline__ void fft_pass(double (&re)[16], double (&im)[16],
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
-                double vr = __dsub_rn(__dmul_rn(re[e1], c), __dmul_rn(im[e1], d));
-                double vi = __dadd_rn(__dmul_rn(re[e1], d), __dmul_rn(im[e1], c));
+                double vr, vi;
+                cmul_annexg<EXACT>(re[e1], im[e1], c, d, vr, vi);
                 re[e1]    = __dsub_rn(re[e0], vr);
                 im[e1]    = __dsub_rn(im[e0], vi);
                 re[e0]    = __dadd_rn(re[e0], vr);
@@ -489,32 +561,32 @@ __device__ __forceinline__ void fft_pass(double (&re)[16], double (&im)[16],
 }
 
 // Whole forward FFT: input tile layout LOGN-4, output tile layout 0.
-template <int LOGN>
+template <int LOGN, bool EXACT = false>
 __device__ __forceinline__ void fft_tiles(double (&re)[16], double (&im)[16],
                                           const double *__restrict__ W, double *plane, int t)
 {
     using G          = XformGeom<LOGN>;
     constexpr int C0 = LOGN - 4;
-    fft_pass<LOGN, C0, 0, 4>(re, im, W, t);
+    fft_pass<LOGN, C0, 0, 4, EXACT>(re, im, W, t);
     constexpr int C1 = G::ntt_c(1);
     redeal<C0, C1>(re, plane, t);
     redeal<C0, C1>(im, plane, t);
-    fft_pass<LOGN, C1, 0, 4>(re, im, W, t);
+    fft_pass<LOGN, C1, 0, 4, EXACT>(re, im, W, t);
     if constexpr (LOGN <= 12)
     {
         redeal<C1, 0>(re, plane, t);
         redeal<C1, 0>(im, plane, t);
-        fft_pass<LOGN, 0, 0, C1>(re, im, W, t);
+        fft_pass<LOGN, 0, 0, C1, EXACT>(re, im, W, t);
     }
     else
     {
         constexpr int C2 = G::ntt_c(2);
         redeal<C1, C2>(re, plane, t);
         redeal<C1, C2>(im, plane, t);
-        fft_pass<LOGN, C2, 0, 4>(re, im, W, t);
+        fft_pass<LOGN, C2, 0, 4, EXACT>(re, im, W, t);
         redeal<C2, 0>(re, plane, t);
         redeal<C2, 0>(im, plane, t);
-        fft_pass<LOGN, 0, 0, C2>(re, im, W, t);
+        fft_pass<LOGN, 0, 0, C2, EXACT>(re, im, W, t);
     }
 }
 

@@ -299,6 +299,49 @@ def test_lower_encode_base_contract(env, golden):
     L.delete_parameters(C.byref(P))
 
 
+@pytest.mark.parametrize("shape", [(1024, 1), (4096, 3), (16384, 6)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_lower_encode_base_nonfinite_values(env, golden, shape):
+    """ckks_encode_base / ifft_inpl under the reference's names on NaN / Inf / FLT_MAX / subnormal / -0.0
+    values: the return value, the index at which the in-place conversion stopped and every int64 before it
+    equal the compiled reference's (goldens) and the oracle's; the unconverted tail is the IFFT output, equal
+    to the oracle's up to the sign / payload bits of NaNs (x86 produces the negative default NaN, the GPU the
+    positive one -- a NaN never reaches an integer output except as INT64_MIN)."""
+    from oracle.pyoracle import Oracle
+    L = _lower(env)
+    L.ifft_inpl.restype = None
+    n, npr = shape
+    o = Oracle(n, npr)
+    P = Parms()
+    imap = np.zeros(n, np.uint16)
+    L.ckks_setup(C.c_size_t(n), C.c_size_t(npr), _vp(imap), C.byref(P))
+    gold = golden["digests"]["shapes"][f"{n}x{npr}"]["encode"]["nonfinite"]
+    conj = np.zeros(n, np.complex128)
+    mids = 0
+    for c in range(V.NONFINITE_CASES):
+        v = V.nonfinite_values(c, n)
+        conj[:] = 0
+        ok = bool(L.ckks_encode_base(C.byref(P), _vp(v), C.c_size_t(n // 2), _vp(imap), None, _vp(conj)))
+        idx, m = o.encode_ex(v)
+        assert idx == gold[c]["fail_index"] and ok == (idx == n), (c, ok, idx)
+        got = conj.view(np.int64)
+        assert (got[:idx] == m[:idx]).all(), c
+        assert V.sha256_hex(got[:idx]) == gold[c]["prefix_sha256"], c
+        mids += 0 < idx < n
+        # tail: raw IFFT output from complex element ceil(idx / 2) on
+        x = np.zeros(n, np.complex128)
+        x[imap[:n // 2]] = v.astype(np.float64)
+        x[imap[n // 2:]] = v.astype(np.float64)
+        full = o.ifft(x)
+        k0 = (idx + 1) // 2
+        assert np.array_equal(conj[k0:].view(np.float64), full[k0:].view(np.float64), equal_nan=True), c
+        # the stand-alone operator on the same (complex) input
+        y = x.copy()
+        L.ifft_inpl(_vp(y), C.c_size_t(n), C.c_size_t(int(np.log2(n))), None)
+        assert np.array_equal(y.view(np.float64), full.view(np.float64), equal_nan=True), c
+    assert mids >= 2
+    L.delete_parameters(C.byref(P))
+
+
 def test_pool_carving_is_the_reference_default_layout(env):
     """ckks_set_ptrs_sym / _asym: offsets of the default configuration (ckks_sym.c:78-160,
     ckks_asym.c:75-157), incl. the c1 == ntt_pte alias of the symmetric pool."""

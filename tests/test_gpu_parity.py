@@ -835,6 +835,115 @@ def test_empty_batch_and_missing_key(env):
         pkg.Context(4096, 4)            # too many primes for n=4096 (parameters.c:212)
 
 
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_nonfinite_values_through_every_path(env, golden, shape):
+    """NaN, +-Inf, FLT_MAX, subnormal and -0.0 plaintext values (tests/vectors.py, nonfinite_values) through
+    every batched entry.  The reference ACCEPTS a NaN coefficient (fabs(NaN) > 2^63 is false,
+    ckks_common.c:195; its x86-64 build stores INT64_MIN) and rejects an infinite one; which coefficients are
+    which is decided by its Annex-G complex product (oracle/se_oracle.c, seo_cmul; transform.cuh,
+    cmul_annexg).  The device's fast kernels decline such plaintexts, the general kernels reproduce them.
+    Checked against the goldens of the compiled reference AND the oracle, ordinary plaintexts interleaved so
+    that one launch mixes fast and general workgroups."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    o = Oracle(n, npr)
+    gold = golden["digests"]["shapes"][f"{n}x{npr}"]["encode"]["nonfinite"]
+    rows, case_of = [], []
+    ordinary = V.bench_values(V.NONFINITE_CASES, n, first=77)
+    for c in range(V.NONFINITE_CASES):
+        rows.append(V.nonfinite_values(c, n)), case_of.append(c)
+        rows.append(ordinary[c]), case_of.append(None)
+    vals = np.stack(rows)
+    B = vals.shape[0]
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=11)
+    ctx.set_secret_key(sk)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    ss, sd = V.bench_seeds(B, first=9000)
+
+    # ckks_encode_base (int64 plaintext + status), and encode + RNS + NTT
+    pte = torch.zeros((B, n), dtype=torch.int64, device=env["dev"])
+    st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encode(dev_t(env, vals), pte, st)
+    out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    pte2 = torch.zeros((B, n), dtype=torch.int64, device=env["dev"])
+    st2 = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encode_ntt(dev_t(env, vals), out, pte=pte2, status=st2)
+    torch.cuda.synchronize()
+    gp, gs, gp2, gs2, gout = pte.cpu().numpy(), st.cpu().numpy(), pte2.cpu().numpy(), st2.cpu().numpy(), host_u32(out)
+    accepted_nan = rejected = 0
+    for b in range(B):
+        idx, m = o.encode_ex(vals[b])
+        ok = idx == n
+        if case_of[b] is not None:
+            g = gold[case_of[b]]
+            assert idx == g["fail_index"], (b, case_of[b])
+            if ok:
+                assert V.sha256_hex(gp[b]) == g["prefix_sha256"], (b, case_of[b])
+                assert int((gp[b] == -2 ** 63).sum()) == g["int64_min_count"]
+                accepted_nan += g["int64_min_count"] > 0
+            rejected += not ok
+        assert bool(gs[b]) == ok and bool(gs2[b]) == ok, (b, case_of[b], gs[b], gs2[b], ok)
+        if ok:
+            assert (gp[b] == m).all() and (gp2[b] == m).all(), (b, case_of[b])
+            for j in range(npr):
+                assert (gout[b, j] == o.ntt(o.reduce_pte(m, j), j)).all(), (b, j)
+    assert accepted_nan >= 3 and rejected >= 5
+
+    # symmetric (fused and split pipelines) and public-key encryption
+    for split in (0, 1):
+        ctx.set_pipeline(1, split)
+        r = ctx.encrypt_sym_host(vals, ss, sd, want_extra=True)
+        ra = ctx.encrypt_asym_host(vals, sd, want_extra=True)
+        for b in range(B):
+            e = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+            ea = o.encrypt_asym(vals[b], sd[b].tobytes(), pk0, pk1)
+            assert bool(r["status"][b]) == e["ok"] and bool(ra["status"][b]) == ea["ok"], (split, b, case_of[b])
+            if e["ok"]:
+                assert (r["pte"][b] == e["pte"]).all(), (split, b, case_of[b])
+                assert (r["c0"][b] == e["c0"]).all() and (r["c1"][b] == e["c1"]).all(), (split, b, case_of[b])
+                assert (ra["c0"][b] == ea["c0"]).all() and (ra["c1"][b] == ea["c1"]).all(), (split, b)
+                if case_of[b] is not None and "c0_sha256" not in gold[case_of[b]]:
+                    raise AssertionError("golden lacks the accepted case")
+    # the compiled reference's own ciphertext digests for the accepted cases (golden seeds)
+    acc = [c for c in range(V.NONFINITE_CASES) if gold[c]["fail_index"] == n]
+    av = np.stack([V.nonfinite_values(c, n) for c in acc])
+    ctx.set_secret_key(V.secret_key(n))
+    sa = np.tile(np.frombuffer(SEED_A, dtype=np.uint8), (len(acc), 1))
+    sb = np.tile(np.frombuffer(SEED_B, dtype=np.uint8), (len(acc), 1))
+    r = ctx.encrypt_sym_host(av, sa, sb, want_extra=True)
+    for i, c in enumerate(acc):
+        assert r["status"][i] == 1
+        assert V.sha256_hex(r["c0"][i]) == gold[c]["c0_sha256"], c
+        assert V.sha256_hex(r["pte"][i]) == gold[c]["pte_sha256"], c
+    ctx.close()
+
+
+def test_nonfinite_plaintexts_fill_a_whole_launch(env):
+    """More NaN plaintexts than the general kernels' grids have workgroups (their queue loops), all of them
+    accepted, every second one ordinary; small batch shape and full-chip shape of the symmetric pipeline."""
+    from oracle.pyoracle import Oracle
+    n, npr, B = 1024, 1, 2300
+    o = Oracle(n, npr)
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n)
+    ctx.set_secret_key(sk)
+    vals = V.bench_values(B, n, first=5)
+    vals[0::2, 3] = np.nan
+    vals[1::4, 7] = np.float32(-0.0)
+    ss, sd = V.bench_seeds(B, first=123)
+    for split in (0, 1):
+        ctx.set_pipeline(1, split)
+        r = ctx.encrypt_sym_host(vals, ss, sd, want_extra=True)
+        assert r["failed"] == 0
+        ok, e0, e1 = o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=8)
+        assert ok and np.array_equal(r["c0"], e0) and np.array_equal(r["c1"], e1), split
+        assert (r["pte"][0::2] == -2 ** 63).sum() > 0
+    ctx.close()
+
+
 def test_overflow_reports_failed_plaintexts(env):
     n = 1024
     ctx = env["pkg"].Context(n, 1)

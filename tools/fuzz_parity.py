@@ -34,7 +34,7 @@ while time.time() - t0 < budget:
         ctx.set_public_key(pk0, pk1)
         ctxs[key] = (ctx, o, sk, pk0, pk1)
     ctx, o, sk, pk0, pk1 = ctxs[key]
-    kind = rng.randrange(5)
+    kind = rng.randrange(6)
     if kind == 0:
         vals = V.bench_values(B, n, seed=case_seed)
     elif kind == 1:
@@ -43,8 +43,19 @@ while time.time() - t0 < budget:
         vals = np.zeros((B, n // 2), dtype=np.float32); vals[:, nr.integers(0, n // 2)] = 1
     elif kind == 3:
         vals = nr.uniform(-30, 30, (B, n // 2)).astype(np.float32)
-    else:   # rows of mixed magnitude: the fast kernels decline some plaintexts of the batch, not others
+    elif kind == 4:   # rows of mixed magnitude: the fast kernels decline some plaintexts of the batch, not others
         vals = (nr.uniform(-30, 30, (B, n // 2)) * nr.choice([0.01, 1.0, 100.0], (B, 1))).astype(np.float32)
+    else:   # NaN / Inf / FLT_MAX / subnormal / -0.0 values in some rows (accepted as INT64_MIN or rejected,
+            # ckks_common.c:195; the general kernels' EXACT transform), ordinary rows between them
+        vals = nr.uniform(-30, 30, (B, n // 2)).astype(np.float32)
+        spec = np.array([np.inf, -np.inf, np.nan, 3.4028235e38, -3.4028235e38, 1e-45, -0.0, 1e-39], dtype=np.float32)
+        for b in range(B):
+            if nr.random() < 0.5:
+                k = int(nr.integers(1, 6))
+                pool = spec[nr.choice(len(spec), size=int(nr.integers(1, 4)), replace=False)]
+                vals[b, nr.choice(n // 2, size=k, replace=False)] = nr.choice(pool, size=k)
+                if nr.random() < 0.15:
+                    vals[b, :] = nr.choice(pool, size=n // 2)
     ss = nr.integers(0, 256, (B, 64), dtype=np.uint8); sd = nr.integers(0, 256, (B, 64), dtype=np.uint8)
     ov, sp = rng.choice([(1, 2), (1, 2), (0, 0), (1, 0), (0, 1), (1, 1)])
     ctx.set_pipeline(ov, sp)
