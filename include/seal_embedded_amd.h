@@ -204,6 +204,48 @@ int se_amd_encrypt_asym_device(se_amd_ctx *ctx, const float *d_values, size_t B,
 int se_amd_encode_ntt_device(se_amd_ctx *ctx, const float *d_values, size_t B, uint32_t *d_out,
                              int64_t *d_pte, uint8_t *d_status, void *stream);
 
+/* ---- device-resident multi-GPU ----------------------------------------------
+ * The path shards embarrassingly (independent plaintexts, own seeds, replicated keys / tables): a GROUP
+ * holds one context per HIP device of one node; a batch of B units is cut into contiguous blocks
+ * (se_amd_group_partition: the first B % ndev members take one more unit) and block i lives on member i's
+ * device -- d_values[i], d_seeds[i], d_c0[i] ... are device pointers ON THAT DEVICE holding count[i]
+ * records.  Every member runs the ordinary batched call on its block, driven by a host thread of its
+ * own on the group's stream for that device; no collective on the data path.  The calls block until
+ * every member has finished.
+ *   gather_root < 0 : outputs stay resident on their devices.
+ *   gather_root = r : additionally every member writes its finished block into its slice of member r's
+ *                     slabs d_c0_all / d_c1_all ([B][np][n] on member r's device, record order = batch
+ *                     order) by peer-to-peer copy on its own stream: on an 8-GPU node 7 concurrent
+ *                     writers over 7 different xGMI links.  A member whose d_c0[i] already points at
+ *                     its slice of the slab (typically the root) is not copied.  d_c1_all may be NULL:
+ *                     only c0 is gathered -- with d_c1 == NULL as well this is the seed-compressed
+ *                     symmetric form (the caller holds the 64-byte shareable seeds; se_amd_expand_c1_device
+ *                     regenerates c1 where it is needed).
+ * devices == NULL / ndev == 0: all visible devices.  The same ordinal may be listed more than once (two
+ * contexts on one GPU) -- used by the single-GPU tests.  The reference has no counterpart: its boundary
+ * is one ciphertext per call (seal_embedded.h:118-124). */
+typedef struct se_amd_group se_amd_group;
+int se_amd_group_create(se_amd_group **out, size_t degree, size_t nprimes, const int *devices, size_t ndev);
+void se_amd_group_destroy(se_amd_group *g);
+size_t se_amd_group_size(const se_amd_group *g);
+se_amd_ctx *se_amd_group_ctx(se_amd_group *g, size_t i); /* member i's context (keys, stage-level calls) */
+int se_amd_group_device(const se_amd_group *g, size_t i);
+int se_amd_group_partition(const se_amd_group *g, size_t B, size_t *first /*[ndev]*/, size_t *count /*[ndev]*/);
+int se_amd_group_set_secret_key(se_amd_group *g, const uint8_t *sk_packed);
+int se_amd_group_set_public_key(se_amd_group *g, const uint32_t *pk0, const uint32_t *pk1);
+int se_amd_group_reserve(se_amd_group *g, size_t B); /* scratch for batches of up to B units in total */
+int se_amd_encrypt_sym_multi_device(se_amd_group *g, size_t B, const float *const *d_values,
+                                    const uint8_t *const *d_share_seeds, const uint8_t *const *d_seeds,
+                                    uint32_t *const *d_c0, uint32_t *const *d_c1 /* NULL: seed-compressed */,
+                                    uint8_t *const *d_status /* NULL or [ndev] */, int gather_root,
+                                    uint32_t *d_c0_all, uint32_t *d_c1_all);
+int se_amd_encrypt_asym_multi_device(se_amd_group *g, size_t B, const float *const *d_values,
+                                     const uint8_t *const *d_seeds, uint32_t *const *d_c0, uint32_t *const *d_c1,
+                                     uint8_t *const *d_status, int gather_root, uint32_t *d_c0_all,
+                                     uint32_t *d_c1_all);
+int se_amd_encode_ntt_multi_device(se_amd_group *g, size_t B, const float *const *d_values, uint32_t *const *d_out,
+                                   uint8_t *const *d_status, int gather_root, uint32_t *d_out_all);
+
 /* Host-pointer entries: synchronous; a chunked pipeline (compute || D2H through a pinned staging
  * ring, or DMA straight into pinned/registered caller memory) that runs at the PCIe link rate.
  * c1 may be NULL for the symmetric form (seed-compressed: only c0 is returned). */

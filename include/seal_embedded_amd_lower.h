@@ -46,6 +46,10 @@ typedef struct SE_PRNG
 void prng_randomize_reset(SE_PRNG *prng, uint8_t *seed_in);
 /* buffer = SHAKE256(seed || le64(counter))[0:byte_count]; counter++ (rng.h:78-91) -- on the GPU */
 void prng_fill_buffer(size_t byte_count, SE_PRNG *prng, void *buffer);
+/* Not in the reference: wipes and frees the device-side operand buffers the lower surface keeps between
+ * calls (packed secret key, u, e / e1, PRNG seeds, m + e) and destroys its per-degree GPU contexts; also
+ * runs at process exit.  The surface stays usable: state is rebuilt on the next call. */
+void se_amd_lower_shutdown(void);
 void prng_clear(SE_PRNG *prng);
 
 /* ---- parameters.h:92-135, modulus.h:41-52 (host-side tables; A1) ---------------------------- */

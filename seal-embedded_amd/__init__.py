@@ -26,9 +26,13 @@ class SealEmbeddedAmdError(RuntimeError):
     pass
 
 
+TESTHOOKS_LIB_DIR = os.path.join(HERE, "lib", "testhooks")   # the -DSEAMD_TEST_HOOKS build (tests only)
+
+
 def build_library(jobs=8, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, f"-j{jobs}"]
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU), and beside it the
+    test build (se_api.cpp under -DSEAMD_TEST_HOOKS: fault injection) the GPU tests link against."""
+    cmd = ["make", "-C", CSRC, f"-j{jobs}", "all", "testhooks"]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
@@ -51,6 +55,9 @@ EXPORTED_SYMBOLS = (
     "se_amd_pack_ternary_host", "se_amd_word_ops_device", "se_amd_pack_seal_ciphertext_host", "se_amd_format_poly_text",
     "se_amd_format_values_text", "se_amd_write_ciphertext_text", "se_amd_save_secret_key_file",
     "se_amd_save_public_key_files", "se_amd_set_profiling", "se_amd_stage_ms",
+    "se_amd_group_create", "se_amd_group_destroy", "se_amd_group_size", "se_amd_group_ctx", "se_amd_group_device",
+    "se_amd_group_partition", "se_amd_group_set_secret_key", "se_amd_group_set_public_key", "se_amd_group_reserve",
+    "se_amd_encrypt_sym_multi_device", "se_amd_encrypt_asym_multi_device", "se_amd_encode_ntt_multi_device",
     "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_set_asym_chunks", "se_amd_last_error", "se_amd_version",
 )
 
@@ -158,6 +165,82 @@ def host_tables(n, nprimes):
     _check(L.se_amd_host_tables(n, nprimes, _ptr(q), _ptr(cr), C.c_void_p(C.addressof(scale)), _ptr(imap), _ptr(w),
                                 _ptr(rw), _ptr(irw)), "se_amd_host_tables")
     return dict(q=q, const_ratio=cr, scale=scale.value, index_map=imap, ifft_w=w, ntt_rw=rw, intt_rw=irw)
+
+
+class Group:
+    """One context per device of a node (se_amd_group): device-resident multi-GPU calls through the C ABI.
+    `blocks` arguments are lists with one torch tensor per member, each on that member's device."""
+
+    def __init__(self, n, nprimes, devices=None):
+        self.L = lib()
+        L = self.L
+        L.se_amd_group_size.restype = C.c_size_t
+        L.se_amd_group_ctx.restype = C.c_void_p
+        L.se_amd_group_ctx.argtypes = [C.c_void_p, C.c_size_t]
+        L.se_amd_group_destroy.restype = None
+        L.se_amd_group_destroy.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        _check(L.se_amd_group_create(C.byref(h), C.c_size_t(n), C.c_size_t(nprimes), arr,
+                                     C.c_size_t(len(devices) if devices else 0)), "se_amd_group_create")
+        self.h, self.n, self.np = h, n, nprimes
+        self.size = int(L.se_amd_group_size(h))
+        self.devices = [int(L.se_amd_group_device(h, C.c_size_t(i))) for i in range(self.size)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.se_amd_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def partition(self, B):
+        first = (C.c_size_t * self.size)()
+        count = (C.c_size_t * self.size)()
+        _check(self.L.se_amd_group_partition(self.h, C.c_size_t(B), first, count), "se_amd_group_partition")
+        return list(first), list(count)
+
+    def set_secret_key(self, sk_packed):
+        import numpy as np
+        sk = np.ascontiguousarray(sk_packed, dtype=np.uint8)
+        _check(self.L.se_amd_group_set_secret_key(self.h, _ptr(sk)), "se_amd_group_set_secret_key")
+
+    def set_public_key(self, pk0, pk1):
+        import numpy as np
+        pk0 = np.ascontiguousarray(pk0, dtype=np.uint32)
+        pk1 = np.ascontiguousarray(pk1, dtype=np.uint32)
+        _check(self.L.se_amd_group_set_public_key(self.h, _ptr(pk0), _ptr(pk1)), "se_amd_group_set_public_key")
+
+    def reserve(self, B):
+        _check(self.L.se_amd_group_reserve(self.h, C.c_size_t(B)), "se_amd_group_reserve")
+
+    def _arr(self, blocks):
+        if blocks is None:
+            return None
+        assert len(blocks) == self.size
+        return (C.c_void_p * self.size)(*[None if t is None else t.data_ptr() for t in blocks])
+
+    def encrypt_sym(self, B, values, share_seeds, seeds, c0, c1=None, status=None, gather_root=-1, c0_all=None,
+                    c1_all=None):
+        _check(self.L.se_amd_encrypt_sym_multi_device(
+            self.h, C.c_size_t(B), self._arr(values), self._arr(share_seeds), self._arr(seeds), self._arr(c0),
+            self._arr(c1), self._arr(status), C.c_int(gather_root), _ptr(c0_all), _ptr(c1_all)),
+            "se_amd_encrypt_sym_multi_device")
+
+    def encrypt_asym(self, B, values, seeds, c0, c1, status=None, gather_root=-1, c0_all=None, c1_all=None):
+        _check(self.L.se_amd_encrypt_asym_multi_device(
+            self.h, C.c_size_t(B), self._arr(values), self._arr(seeds), self._arr(c0), self._arr(c1),
+            self._arr(status), C.c_int(gather_root), _ptr(c0_all), _ptr(c1_all)),
+            "se_amd_encrypt_asym_multi_device")
+
+    def encode_ntt(self, B, values, out, status=None, gather_root=-1, out_all=None):
+        _check(self.L.se_amd_encode_ntt_multi_device(
+            self.h, C.c_size_t(B), self._arr(values), self._arr(out), self._arr(status), C.c_int(gather_root),
+            _ptr(out_all)), "se_amd_encode_ntt_multi_device")
 
 
 class Context:

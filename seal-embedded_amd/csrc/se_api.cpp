@@ -41,9 +41,12 @@ int se_amd_create(se_amd_ctx **out, size_t degree, size_t nprimes, int device)
     *out          = nullptr;
     // The small-batch path runs one sampler launch per prime on streams of their own; with the ROCm
     // default of 4 hardware queues per process some of them share a queue and serialise (n = 16384 /
-    // 6 primes: 12.9 ms per call instead of 7.0 ms; 3-prime chains fit 4 queues).  Ask for more queues unless the caller decided otherwise;
-    // only effective when this is the first HIP use of the process (the C-API case).
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // 6 primes: 12.9 ms per call instead of 7.0 ms; 3-prime chains fit 4 queues).  The library does not
+    // touch the host process's environment on its own: a caller who wants the extra queues exports
+    // GPU_MAX_HW_QUEUES itself, or opts in with SE_AMD_HW_QUEUES=<n>, which is applied here -- and only
+    // effective when this is the first HIP use of the process.
+    if (const char *hq = getenv("SE_AMD_HW_QUEUES"))
+        if (atoi(hq) > 0) setenv("GPU_MAX_HW_QUEUES", hq, 0);
     se_amd_ctx *h = new (std::nothrow) se_amd_ctx();
     if (!h) return SE_ERR_NO_MEMORY;
     int rc = h->c.init(degree, nprimes, device);
@@ -167,20 +170,7 @@ int se_amd_encrypt_sym_seeded_device(se_amd_ctx *ctx, const float *d_values, siz
                                      uint32_t *d_c0, uint8_t *d_status, void *stream)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;
-    Context &c = ctx->c;
-    if (B > c.a_cap)
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        SEAMD_HIP(hipSetDevice(c.device));
-        SEAMD_HIP(hipDeviceSynchronize());
-        if (c.d_a) (void)hipFree(c.d_a);
-        c.d_a   = nullptr;
-        c.a_cap = 0;
-        SEAMD_HIP(hipMalloc((void **)&c.d_a, B * c.hp.nprimes * c.hp.n * sizeof(uint32_t)));
-        c.a_cap = B;
-    }
-    return c.encrypt_sym(d_values, B, d_share_seeds, d_seeds, d_c0, c.d_a, nullptr, nullptr, d_status,
-                         as_stream(stream));
+    return ctx->c.encrypt_sym_seeded(d_values, B, d_share_seeds, d_seeds, d_c0, d_status, as_stream(stream));
 }
 
 int se_amd_expand_c1_device(se_amd_ctx *ctx, const uint8_t *d_share_seeds, size_t B, uint32_t *d_c1,
@@ -652,6 +642,23 @@ bool se_encrypt_seeded(uint8_t *shareable_seed, uint8_t *seed, SEND_FNCT_PTR net
     // one GPU call for the whole ciphertext (all primes), then the reference's per-prime delivery
     std::vector<uint32_t> c0(np * n), c1(np * n), ntt_pte(np * n);
     std::vector<int64_t> pte(n);
+    std::vector<int8_t> codes(parms->is_asymmetric ? n : 0);
+    // the private seed, m + e and u do not outlive the call on the host (SE_PTRS keeps what the
+    // reference keeps there)
+    struct Wipe
+    {
+        uint8_t *seed;
+        std::vector<int64_t> &pte;
+        std::vector<int8_t> &codes;
+        std::vector<uint32_t> &ntt_pte;
+        ~Wipe()
+        {
+            explicit_bzero(seed, 64);
+            explicit_bzero(pte.data(), pte.size() * sizeof(int64_t));
+            explicit_bzero(codes.data(), codes.size());
+            explicit_bzero(ntt_pte.data(), ntt_pte.size() * sizeof(uint32_t));
+        }
+    } wipe{s_priv, pte, codes, ntt_pte};
     int rc;
     if (parms->is_asymmetric)
         rc = se_amd_encrypt_asym_host(g_ctx, ptrs->values, 1, s_priv, c0.data(), c1.data(),
@@ -669,7 +676,6 @@ bool se_encrypt_seeded(uint8_t *shareable_seed, uint8_t *seed, SEND_FNCT_PTR net
     memcpy(ptrs->conj_vals_int_ptr, pte.data(), n * sizeof(int64_t));
     if (parms->is_asymmetric)
     {
-        std::vector<int8_t> codes(n);
         if (g_ctx->c.fetch_asym_randomness(codes.data(), ptrs->e1_ptr) != 0)
         {
             fprintf(stderr, "Error! se_encrypt: %s\n", se_amd_last_error());
@@ -760,7 +766,9 @@ int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
         const size_t lo = B * d / ndev, hi = B * (d + 1) / ndev;
         se_amd_ctx *ctx = d == 0 ? g_ctx : g_more[d - 1];
         workers.emplace_back([&, d, lo, hi, ctx] {
-            // fault injection for the re-run path (tests): $SE_AMD_INJECT_SHARD_FAILURE = shard index
+#ifdef SEAMD_TEST_HOOKS
+            // fault injection for the re-run path: $SE_AMD_INJECT_SHARD_FAILURE = shard index.  Compiled
+            // into the test build of the library only (make testhooks), never into the product.
             const char *inj = getenv("SE_AMD_INJECT_SHARD_FAILURE");
             if (inj && *inj && (size_t)atol(inj) == d)
             {
@@ -768,24 +776,31 @@ int se_encrypt_batch(const SE_PARMS *se_parms, const float *values, size_t B,
                 errs[d] = "injected shard failure";
                 return;
             }
+#endif
             rcs[d] = run(ctx, lo, hi - lo);
             if (rcs[d] < 0) errs[d] = se_amd_last_error();  // thread-local: carry it to the caller
         });
     }
     for (auto &w : workers) w.join();
-    // A failed shard is re-run on a device whose own shard succeeded (units are
-    // independent, so a lost device costs time, not results); only if that fails too is the error returned.
+    // A shard lost to a DEVICE failure (a HIP error, a device that went away) is re-run on a device whose
+    // own shard succeeded in the first pass (units are independent, so a lost device
+    // costs time, not results).  Caller errors (invalid argument, missing key) fail on every device alike
+    // and are returned as they are.  `healthy` is fixed after the first pass: a device that failed once is
+    // never chosen as a fallback, whatever happened to its shard afterwards.
+    std::vector<char> healthy(ndev);
+    for (size_t d = 0; d < ndev; d++) healthy[d] = rcs[d] >= 0;
     int failed = 0;
     for (size_t d = 0; d < ndev; d++)
     {
         if (rcs[d] < 0)
         {
+            const bool device_fault = rcs[d] == SE_ERR_HIP || rcs[d] == SE_ERR_NO_DEVICE;
             const size_t lo = B * d / ndev, hi = B * (d + 1) / ndev;
             int rc = rcs[d];
-            for (size_t k = 1; k < ndev && rc < 0; k++)
+            for (size_t k = 1; device_fault && k < ndev && rc < 0; k++)
             {
                 const size_t h = (d + k) % ndev;
-                if (rcs[h] < 0) continue;
+                if (!healthy[h]) continue;
                 se_amd_ctx *ctx = h == 0 ? g_ctx : g_more[h - 1];
                 fprintf(stderr, "se_encrypt_batch: shard %zu (ciphertexts %zu..%zu) failed (%s); re-running it on "
                                 "device slot %zu\n", d, lo, hi, errs[d].c_str(), h);

@@ -288,6 +288,12 @@ int Context::fetch_asym_randomness(int8_t *ucodes, int8_t *e1)
 int Context::set_secret_key(const uint8_t *sk_packed)
 {
     std::lock_guard<std::mutex> lk(mu);
+    return set_secret_key_impl(sk_packed);
+}
+
+// the caller holds `mu`
+int Context::set_secret_key_impl(const uint8_t *sk_packed)
+{
     const size_t n = hp.n, np = hp.nprimes;
     SEAMD_HIP(hipSetDevice(device));
     std::vector<uint32_t> expanded(np * n);
@@ -361,9 +367,10 @@ int Context::set_public_key(const uint32_t *pk0, const uint32_t *pk1)
 int Context::gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, const uint8_t *ep_seed,
                             uint32_t *pk0_out, uint32_t *pk1_out)
 {
-    int rc = set_secret_key(sk_packed);
-    if (rc) return rc;
+    // one critical section: the key the public key is derived from is the key that stays installed
     std::lock_guard<std::mutex> lk(mu);
+    int rc = set_secret_key_impl(sk_packed);
+    if (rc) return rc;
     rc = ensure_scratch(1);
     if (rc) return rc;
     const uint32_t n = (uint32_t)hp.n, np = (uint32_t)hp.nprimes;
@@ -403,7 +410,11 @@ int Context::gen_keys_batch(size_t K, const uint8_t *sk_in, const uint8_t *sk_se
                             const uint8_t *ep_seeds, uint8_t *sk_out, uint32_t *pk0_out, uint32_t *pk1_out)
 {
     if (K == 0) return 0;
-    if ((!sk_in && !sk_seeds) || !pk_seeds || !ep_seeds || !pk0_out || !pk1_out) return kErrInvalid;
+    if ((!sk_in && !sk_seeds) || !pk_seeds || !ep_seeds || !pk0_out || !pk1_out)
+    {
+        set_last_error("gen_keys_batch: sk_in or sk_seeds, pk_seeds, ep_seeds and both output slabs are required");
+        return kErrInvalid;
+    }
     std::lock_guard<std::mutex> lk(mu);
     SEAMD_HIP(hipSetDevice(device));
     int rc = ensure_scratch(K);
@@ -491,6 +502,30 @@ int Context::encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share
     int rc = begin_call(st);
     if (rc) return rc;
     rc = encrypt_sym_impl(d_values, B, d_share_seeds, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte, d_status, st);
+    return end_call(st, rc);
+}
+
+// Seed-compressed form: `a` goes to context scratch instead of a caller slab.  The scratch is grown, and
+// its pointer handed to the kernels, inside ONE critical section -- a concurrent call with a larger batch
+// cannot free it under a call that is still being launched (and the launched work is ordered behind
+// ev_done like every other use of the context's scratch).
+int Context::encrypt_sym_seeded(const float *d_values, size_t B, const uint8_t *d_share_seeds,
+                                const uint8_t *d_seeds, uint32_t *d_c0, uint8_t *d_status, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    SEAMD_HIP(hipSetDevice(device));
+    if (B > a_cap)
+    {
+        SEAMD_HIP(hipDeviceSynchronize());   // earlier calls may still read the old slab
+        if (d_a) (void)hipFree(d_a);
+        d_a   = nullptr;
+        a_cap = 0;
+        SEAMD_HIP(hipMalloc((void **)&d_a, B * hp.nprimes * hp.n * sizeof(uint32_t)));
+        a_cap = B;
+    }
+    int rc = begin_call(st);
+    if (rc) return rc;
+    rc = encrypt_sym_impl(d_values, B, d_share_seeds, d_seeds, d_c0, d_a, nullptr, nullptr, d_status, st);
     return end_call(st, rc);
 }
 

@@ -117,6 +117,7 @@ struct Context
     // u codes (0/1/2 per coefficient) and e1 of ciphertext 0 of the last asymmetric call (host out)
     int fetch_asym_randomness(int8_t *ucodes, int8_t *e1);
     int set_secret_key(const uint8_t *sk_packed);
+    int set_secret_key_impl(const uint8_t *sk_packed);   // caller holds `mu`
     int set_public_key(const uint32_t *pk0, const uint32_t *pk1);
     int gen_public_key(const uint8_t *sk_packed, const uint8_t *pk_seed, const uint8_t *ep_seed,
                        uint32_t *pk0_out, uint32_t *pk1_out);
@@ -128,6 +129,8 @@ struct Context
     int encrypt_sym(const float *d_values, size_t B, const uint8_t *d_share_seeds,
                     const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,
                     int64_t *d_pte, uint8_t *d_status, hipStream_t st);
+    int encrypt_sym_seeded(const float *d_values, size_t B, const uint8_t *d_share_seeds,
+                           const uint8_t *d_seeds, uint32_t *d_c0, uint8_t *d_status, hipStream_t st);
     int encrypt_asym(const float *d_values, size_t B, const uint8_t *d_seeds, uint32_t *d_c0,
                      uint32_t *d_c1, uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status,
                      hipStream_t st);

@@ -68,6 +68,7 @@ struct Lower
     se_amd_ctx *h = nullptr;
     size_t n      = 0;
     uint8_t *slab = nullptr;
+    size_t slab_bytes = 0;
     double *cplx_in = nullptr, *cplx_out = nullptr;  // [n][2]
     int64_t *i64     = nullptr;                      // [n]
     uint32_t *u32[8] = {};                           // [n] each
@@ -83,6 +84,61 @@ struct Lower
 
 std::map<size_t, Lower *> g_lower;
 
+// prng_fill_buffer's own device scratch (a pure PRNG call needs no parameter set)
+struct PrngScratch
+{
+    int device     = 0;
+    bool ready     = false;
+    uint8_t *seed  = nullptr;   // [64]
+    uint64_t *ctr  = nullptr;   // [1]
+    uint8_t *bytes = nullptr;
+    size_t cap     = 0;
+} g_prng;
+
+// The operand slabs hold secrets between calls (packed secret key, u, e / e1, PRNG seeds, m + e):
+// se_amd_lower_shutdown() -- also run at process exit -- wipes and frees them and destroys the per-degree
+// contexts.  The surface stays usable afterwards (state is rebuilt on the next call).
+void lower_shutdown()
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    for (auto &kv : g_lower)
+    {
+        Lower *L = kv.second;
+        if (hipSetDevice(L->c().device) == hipSuccess)
+        {
+            (void)hipDeviceSynchronize();
+            if (L->slab) (void)hipMemset(L->slab, 0, L->slab_bytes);
+            if (L->bytes) (void)hipMemset(L->bytes, 0, L->bytes_cap);
+            (void)hipDeviceSynchronize();
+            if (L->slab) (void)hipFree(L->slab);
+            if (L->bytes) (void)hipFree(L->bytes);
+        }
+        se_amd_destroy(L->h);
+        delete L;
+    }
+    g_lower.clear();
+    if (g_prng.ready && hipSetDevice(g_prng.device) == hipSuccess)
+    {
+        (void)hipMemset(g_prng.seed, 0, 64);
+        (void)hipMemset(g_prng.ctr, 0, 8);
+        if (g_prng.bytes) (void)hipMemset(g_prng.bytes, 0, g_prng.cap);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_prng.seed), (void)hipFree(g_prng.ctr);
+        if (g_prng.bytes) (void)hipFree(g_prng.bytes);
+    }
+    g_prng = PrngScratch();
+}
+
+void register_shutdown()
+{
+    static bool registered = false;
+    if (!registered)
+    {
+        registered = true;
+        atexit(lower_shutdown);
+    }
+}
+
 Lower &lower_for_degree(size_t n)
 {
     auto it = g_lower.find(n);
@@ -93,6 +149,7 @@ Lower &lower_for_degree(size_t n)
         fprintf(stderr, "Error! unsupported polynomial degree %zu (parameters.c:176-230)\n", n);
         exit(1);
     }
+    register_shutdown();
     Lower *L = new Lower();
     L->n     = n;
     int dev  = getenv("SE_AMD_DEVICE") ? atoi(getenv("SE_AMD_DEVICE")) : 0;
@@ -101,6 +158,7 @@ Lower &lower_for_degree(size_t n)
     size_t total = 16 * n * 2 + 8 * n + 8 * 4 * n + 2 * n + n / 4 + 64 + 16 + 16;
     LOWER_HIP(hipSetDevice(L->c().device));
     LOWER_HIP(hipMalloc((void **)&L->slab, total));
+    L->slab_bytes = total;
     uint8_t *p  = L->slab;
     L->cplx_in  = (double *)p, p += 16 * n;
     L->cplx_out = (double *)p, p += 16 * n;
@@ -210,21 +268,47 @@ void prng_clear(SE_PRNG *prng)
     prng->counter = 0;
 }
 
+void se_amd_lower_shutdown(void) { lower_shutdown(); }
+
+// A pure PRNG call needs no parameter set: it has device scratch of its own (seed, counter, growable
+// output buffer on $SE_AMD_DEVICE) instead of borrowing -- or creating -- a per-degree context.
 void prng_fill_buffer(size_t byte_count, SE_PRNG *prng, void *buffer)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    Lower &L = g_lower.empty() ? lower_for_degree(4096) : *g_lower.begin()->second;
-    LOWER_HIP(hipSetDevice(L.c().device));
-    if (byte_count > L.bytes_cap)
+    if (byte_count > 0xFFFFFFFFu)
     {
-        if (L.bytes) (void)hipFree(L.bytes);
-        L.bytes = nullptr, L.bytes_cap = 0;
-        LOWER_HIP(hipMalloc((void **)&L.bytes, byte_count));
-        L.bytes_cap = byte_count;
+        // one call = ONE SHAKE256 squeeze (rng.h:78-91); the kernel counts output bytes in 32 bits
+        fprintf(stderr, "Error! prng_fill_buffer: %zu bytes in one call (limit 4 GiB - 1)\n", byte_count);
+        exit(1);
     }
-    put_prng(L, prng);
-    LOWER_HIP(seamd::launch_prng_blocks(L.seed, L.ctr, L.bytes, (uint32_t)byte_count, 1, nullptr));
-    down(buffer, L.bytes, byte_count);
+    if (!g_prng.ready)
+    {
+        register_shutdown();
+        g_prng.device = getenv("SE_AMD_DEVICE") ? atoi(getenv("SE_AMD_DEVICE")) : 0;
+        LOWER_HIP(hipSetDevice(g_prng.device));
+        LOWER_HIP(hipMalloc((void **)&g_prng.seed, 64));
+        LOWER_HIP(hipMalloc((void **)&g_prng.ctr, 8));
+        g_prng.ready = true;
+    }
+    LOWER_HIP(hipSetDevice(g_prng.device));
+    if (byte_count > g_prng.cap)
+    {
+        if (g_prng.bytes)
+        {
+            (void)hipMemset(g_prng.bytes, 0, g_prng.cap);   // PRNG output of a secret seed
+            (void)hipFree(g_prng.bytes);
+        }
+        g_prng.bytes = nullptr, g_prng.cap = 0;
+        LOWER_HIP(hipMalloc((void **)&g_prng.bytes, byte_count ? byte_count : 1));
+        g_prng.cap = byte_count ? byte_count : 1;
+    }
+    up(g_prng.seed, prng->seed, 64);
+    up(g_prng.ctr, &prng->counter, 8);
+    if (byte_count)
+    {
+        LOWER_HIP(seamd::launch_prng_blocks(g_prng.seed, g_prng.ctr, g_prng.bytes, (uint32_t)byte_count, 1, nullptr));
+        down(buffer, g_prng.bytes, byte_count);
+    }
     const uint64_t before = prng->counter;
     prng->counter++;
     after_draws(prng, before);

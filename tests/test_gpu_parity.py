@@ -1204,13 +1204,16 @@ def test_reference_api_callback_stream(env, golden, tmp_path):
 
 
 # --------------------------------------------------------------------------- C callers (examples/)
-def _build_example(name, tmp_path):
+def _build_example(name, tmp_path, hip=False):
     import subprocess
     exe = tmp_path / name
     lib = os.path.join(ROOT, "seal-embedded_amd", "lib")
-    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", os.path.join(ROOT, "examples", name + ".c"),
-                    "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lseal_embedded_amd",
-                    "-Wl,-rpath," + lib, "-o", str(exe)], check=True)
+    cmd = ["gcc", "-std=gnu11", "-Wall", "-Werror", os.path.join(ROOT, "examples", name + ".c"),
+           "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lseal_embedded_amd", "-Wl,-rpath," + lib, "-o", str(exe)]
+    if hip:   # a C caller that owns device memory: the HIP runtime's C API, still plain gcc
+        cmd += ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64",
+                "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
     return exe
 
 
@@ -1270,6 +1273,12 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
         # a shard whose device "fails" (fault injection) is re-run on a healthy one: same records
         inject, devices = devices.split(":", 1)
         e["SE_AMD_INJECT_SHARD_FAILURE"] = inject[len("inject"):]
+        # the hook exists only in the test build of the library (make testhooks, -DSEAMD_TEST_HOOKS), which
+        # the loader finds first through LD_LIBRARY_PATH; the product ignores the variable (checked below)
+        ignored = subprocess.run([str(exe), str(n), str(npr), str(B)], env=dict(e, SE_AMD_DEVICES=devices),
+                                 check=True, capture_output=True, text=True, timeout=300)
+        assert "re-running" not in ignored.stderr
+        e["LD_LIBRARY_PATH"] = env["pkg"].TESTHOOKS_LIB_DIR + os.pathsep + e.get("LD_LIBRARY_PATH", "")
     if devices and devices.startswith("visible:"):
         e["HIP_VISIBLE_DEVICES"] = "0"
         devices = devices.split(":", 1)[1]
@@ -1302,6 +1311,130 @@ def test_c_caller_of_batch_entry(env, tmp_path, devices):
             first = h
     assert kv["failed"] == "0"
     assert kv["first"] == "%016x" % first and kv["all"] == "%016x" % h
+
+
+@pytest.mark.parametrize("devices,B", [("0", 7), ("0,0", 7), ("0,0,0", 200), ("0,0,0,0,0,0,0,0", 5)])
+def test_c_caller_of_multi_device_entry(env, tmp_path, devices, B):
+    """examples/multi_device_encrypt.c: se_amd_encrypt_sym_multi_device from plain C with hipMalloc'ed blocks
+    (one per group member, inputs and outputs resident on the member's device) and the peer-to-peer gather
+    into the root's slab, the root producing its block in place.  The gathered records equal the oracle's in
+    batch order however many members the batch is cut over (a single-GPU box lists the same ordinal
+    several times: separate contexts, streams and host threads; 5 units over 8 members leaves members with
+    EMPTY blocks, 7 over 2 and 200 over 3 unequal ones)."""
+    import subprocess
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    n, npr = 1024, 1
+    exe = _build_example("multi_device_encrypt", tmp_path, hip=True)
+    sk = V.secret_key(n)
+    skf = tmp_path / "sk.dat"
+    sk.tofile(skf)
+    res = subprocess.run([str(exe), str(n), str(npr), str(B), devices, str(skf)], check=True, capture_output=True,
+                         text=True, timeout=300)
+    kv = dict(f.split("=") for f in [l for l in res.stdout.splitlines() if l.startswith("failed=")][-1].split())
+    assert kv["failed"] == "0" and int(kv["devices"]) == len(devices.split(","))
+    o = Oracle(n, npr)
+    h = 0xcbf29ce484222325
+    for b in range(B):
+        i = np.arange(n // 2, dtype=np.uint64) + np.uint64(b)
+        with np.errstate(over="ignore"):
+            v = ((i * np.uint64(2654435761)) % np.uint64(100000)).astype(np.float64) / 1000 - 50
+        share = bytes((k + b) & 255 for k in range(64))
+        seed = bytes((255 - k + 3 * b) & 255 for k in range(64))
+        r = o.encrypt_sym(v.astype(np.float32), share, seed, sk)
+        for j in range(npr):
+            h = pyoracle.fnv1a64(r["c0"][j].tobytes(), h)
+            h = pyoracle.fnv1a64(r["c1"][j].tobytes(), h)
+    assert kv["all"] == "%016x" % h
+
+
+@pytest.mark.parametrize("mode", ["sym", "sym_seeded", "asym", "encode"])
+def test_group_entries_match_single_device(env, mode):
+    """The three multi-device entries through ctypes (se_amd_group over the same GPU listed three times):
+    resident outputs, gathered outputs with an in-place root block, the seed-compressed symmetric form
+    (c1 == NULL: only c0 travels) -- all bit-identical to one single-context call on the whole batch."""
+    torch = env["torch"]
+    from oracle.pyoracle import Oracle
+    n, npr, B = 4096, 3, 301
+    dev = env["dev"]
+    sk = V.secret_key(n, seed=21)
+    o = Oracle(n, npr)
+    ctx = env["pkg"].Context(n, npr)
+    ctx.set_secret_key(sk)
+    pk0, pk1 = o.gen_pk(sk, SEED_PK, SEED_EP)
+    ctx.set_public_key(pk0, pk1)
+    vals = V.bench_values(B, n, first=31)
+    ss, sd = V.bench_seeds(B, first=31)
+    tv, tss, tsd = dev_t(env, vals), dev_t(env, ss), dev_t(env, sd)
+    e0 = torch.zeros((B, npr, n), dtype=torch.int32, device=dev)
+    e1 = torch.zeros_like(e0)
+    if mode in ("sym", "sym_seeded"):
+        ctx.encrypt_sym(tv, tss, tsd, e0, e1)
+    elif mode == "asym":
+        ctx.encrypt_asym(tv, tsd, e0, e1)
+    else:
+        ctx.encode_ntt(tv, e0)
+    torch.cuda.synchronize()
+
+    g = env["pkg"].Group(n, npr, devices=[0, 0, 0])
+    assert g.size == 3 and g.devices == [0, 0, 0]
+    g.set_secret_key(sk)
+    g.set_public_key(pk0, pk1)
+    g.reserve(B)
+    first, count = g.partition(B)
+    assert sum(count) == B and first == [0, count[0], count[0] + count[1]] and max(count) - min(count) <= 1
+    blk = lambda t: [t[f:f + c].contiguous() for f, c in zip(first, count)]
+    bv, bss, bsd = blk(tv), blk(tss), blk(tsd)
+    c0_all = torch.full((B, npr, n), -1, dtype=torch.int32, device=dev)
+    c1_all = torch.full((B, npr, n), -1, dtype=torch.int32, device=dev)
+    root = 1
+    # member `root` writes in place inside the slab, the others into blocks of their own
+    c0 = [c0_all[f:f + c] if i == root else torch.zeros((c, npr, n), dtype=torch.int32, device=dev)
+          for i, (f, c) in enumerate(zip(first, count))]
+    c1 = [c1_all[f:f + c] if i == root else torch.zeros((c, npr, n), dtype=torch.int32, device=dev)
+          for i, (f, c) in enumerate(zip(first, count))]
+    st = [torch.zeros(c, dtype=torch.uint8, device=dev) for c in count]
+    if mode == "sym":
+        g.encrypt_sym(B, bv, bss, bsd, c0, c1, st, gather_root=root, c0_all=c0_all, c1_all=c1_all)
+    elif mode == "sym_seeded":
+        g.encrypt_sym(B, bv, bss, bsd, c0, None, st, gather_root=root, c0_all=c0_all)
+    elif mode == "asym":
+        g.encrypt_asym(B, bv, bsd, c0, c1, st, gather_root=root, c0_all=c0_all, c1_all=c1_all)
+    else:
+        g.encode_ntt(B, bv, c0, st, gather_root=root, out_all=c0_all)
+    torch.cuda.synchronize()
+    assert all(bool(s.all()) for s in st)
+    assert torch.equal(c0_all, e0)
+    if mode in ("sym", "asym"):
+        assert torch.equal(c1_all, e1)
+    elif mode == "sym_seeded":
+        assert bool((c1_all == -1).all())                     # untouched: only c0 travels
+        ctx.expand_c1(tss, c1_all)
+        torch.cuda.synchronize()
+        assert torch.equal(c1_all, e1)
+    for i, (f, c) in enumerate(zip(first, count)):            # the resident blocks themselves
+        assert torch.equal(c0[i], e0[f:f + c])
+    # resident form (no gather), B smaller than the group: members with empty blocks
+    small = 2
+    f2, n2 = g.partition(small)
+    assert n2 == [1, 1, 0]
+    o0 = [torch.zeros((max(c, 1), npr, n), dtype=torch.int32, device=dev) for c in n2]
+    o1 = [torch.zeros((max(c, 1), npr, n), dtype=torch.int32, device=dev) for c in n2]
+    bb = lambda t: [t[f:f + c].contiguous() if c else None for f, c in zip(f2, n2)]
+    if mode in ("sym", "sym_seeded"):
+        g.encrypt_sym(small, bb(tv), bb(tss), bb(tsd), o0, o1)
+    elif mode == "asym":
+        g.encrypt_asym(small, bb(tv), bb(tsd), o0, o1)
+    else:
+        g.encode_ntt(small, bb(tv), o0)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(o0[i][0], e0[i])
+    # argument errors are reported, not crashed on
+    with pytest.raises(env["pkg"].SealEmbeddedAmdError):
+        g.encode_ntt(B, bv, c0, st, gather_root=7, out_all=c0_all)
+    g.close()
+    ctx.close()
 
 
 # --------------------------------------------------------------------------- device word arithmetic

@@ -174,3 +174,47 @@ def test_bench_line_survives_a_rank_lost_in_the_gather(tmp_path):
         os.environ.pop("SE_BENCH_DEADLINE_S", None)
     assert "incomplete" in d and d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
     assert d["gather"]["form"] == "full" and "error" in d["gather"]
+
+
+def _run_bench_plain(extra, tmp_path, env_extra=None):
+    """`python bench.py ...` as the driver's single-GPU command line spells it: NO torch.distributed.run
+    around it, no WORLD_SIZE in the environment."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SE_BENCH_STUB="stub_context", PYTHONPATH=os.path.join(root, "tests"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True,
+                       text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself (torch.distributed.run on
+    127.0.0.1, a free port) and prints the same ONE line: n_gpus = 2, the whole-job rate, the gather, and
+    every rank's own step time next to the process group's world size."""
+    d, _ = _run_bench_plain(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c1", "--batch", "3",
+                             "--others", "none"], tmp_path)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 6 and "requested_gpus" not in d
+    assert d["ranks"]["world_size"] == 2 and len(d["ranks"]["ms_per_step"]) == 2
+    assert all(t is not None and t > 0 for t in d["ranks"]["ms_per_step"])
+    assert abs(max(d["ranks"]["ms_per_step"]) - d["ms_per_step"]) < 1e-9       # the line's time is the max
+    assert d["gather"]["form"] == "full"
+
+
+def test_bench_with_fewer_devices_than_requested(tmp_path):
+    """--gpus 4 on a box that shows 2 devices, and --gpus 8 on one that shows 1: the run does not die; it
+    measures on the devices there are and the line says so (n_gpus = what ran, requested_gpus, note)."""
+    d, err = _run_bench_plain(["--gpus", "4", "--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "2",
+                               "--others", "none"], tmp_path, {"SE_BENCH_STUB_DEVICES": "2"})
+    assert d["n_gpus"] == 2 and d["requested_gpus"] == 4 and "only 2 device(s)" in d["note"]
+    assert "4 requested, 2 device(s) visible" in err
+    d, _ = _run_bench_plain(["--gpus", "8", "--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "2",
+                             "--others", "none"], tmp_path, {"SE_BENCH_STUB_DEVICES": "1"})
+    assert d["n_gpus"] == 1 and d["requested_gpus"] == 8 and d["value"] > 0 and "ranks" not in d

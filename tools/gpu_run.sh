@@ -9,7 +9,7 @@ ubench) ( timeout 120 ./tools/ubench ) > gpurun_out/ubench.log 2>&1; cat gpurun_
 ubench2) ( timeout 120 ./tools/ubench2 ) > gpurun_out/ubench2.log 2>&1; cat gpurun_out/ubench2.log;;
 tests) ( timeout 2400 python -m pytest tests -m gpu -q --tb=short --timeout=900 ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
 bench) ( timeout 900 python bench.py ) > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log; tail -3 gpurun_out/bench.log;;
-dist1) ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --batch 16384 --no-cpu-baseline --gather ) > gpurun_out/dist1.log 2>&1; tail -3 gpurun_out/dist1.log; ( WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --batch 8192 --no-cpu-baseline --gather ) > gpurun_out/dist1b.log 2>&1; tail -2 gpurun_out/dist1b.log;;
+dist1) ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --batch 16384 --no-cpu-baseline --others none ) > gpurun_out/dist1.log 2>&1; tail -1 gpurun_out/dist1.log | cut -c1-400; ( timeout 600 python bench.py --gpus 8 --steps 3 --warmup 1 --batch 8192 --no-cpu-baseline --others none ) > gpurun_out/dist1b.log 2>&1; tail -1 gpurun_out/dist1b.log | cut -c1-400; ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 3 --warmup 1 --batch 8192 --no-cpu-baseline --others none ) > gpurun_out/dist1c.log 2>&1; tail -1 gpurun_out/dist1c.log | cut -c1-600;;
 benchc5) for w in c5; do ( timeout 900 python bench.py --steps 5 --warmup 1 --workload $w --no-cpu-baseline ) > gpurun_out/bench_$w.log 2>&1; tail -1 gpurun_out/bench_$w.log; done;;
 benchc3) for w in c3; do ( timeout 900 python bench.py --steps 5 --warmup 1 --workload $w --no-cpu-baseline ) > gpurun_out/bench_$w.log 2>&1; tail -1 gpurun_out/bench_$w.log; done;;
 benchall) for w in c3 c5 c4 c1; do ( timeout 900 python bench.py --steps 5 --warmup 1 --workload $w --no-cpu-baseline ) > gpurun_out/bench_$w.log 2>&1; tail -1 gpurun_out/bench_$w.log; done;;
