@@ -194,4 +194,240 @@ __device__ __forceinline__ void prng_absorb(KeccakState &s, const uint32_t (&see
     s.hi[16] = 0x80000000u;
 }
 
+// ------------------------------------------------------------------------------------------
+// Pair-cooperative form: ONE state over TWO adjacent lanes (2k, 2k + 1).
+//
+// A chain kernel's ciphertext is a sequential sponge squeeze (121 permutations per prime at n = 4096, 482 at
+// n = 16384): with one state per lane its latency is 24 x 190 instructions of ONE wave, whatever the batch
+// size, and a batch smaller than the chip leaves SIMDs empty.  Here the even lane of a pair holds the LOW
+// 32-bit halves of the 25 state lanes, the odd lane the HIGH halves (25 VGPRs each).  theta's parities, the
+// application of D, chi and iota are half-local; only a 64-bit rotation needs the partner's half of the same
+// state lane: one v_mov_b32_dpp quad_perm:[1,0,3,2] (a VALU move -- no LDS, no barrier) per rotated word, and
+// the SAME instruction sequence serves both lanes:
+//     R < 32 : lo' = lo << R | hi >> (32-R),  hi' = hi << R | lo >> (32-R)   = alignbit(own, partner, 32 - R)
+//     R > 32 : lo' = hi << (R-32) | lo >> (64-R),  hi' likewise              = alignbit(partner, own, 64 - R)
+// Per round and lane: 10 (parities) + 5 + 5 + 5 (D) + 25 (apply) + 24 + 24 (rho) + 25 (chi) + 3 (iota) = 126
+// VALU instructions against 190 for the lane-per-state form: the chain of one ciphertext gets 1.5x shorter,
+// the chip does 1.33x the work -- a win exactly where the lane-per-state form leaves SIMDs idle (small
+// batches, single calls), a loss on a full chip.  Bit-identical by construction: the
+// same Boolean function of keccakf1600.c:51-316, other registers.
+// ------------------------------------------------------------------------------------------
+struct KeccakHalf
+{
+    uint32_t w[25];   // even lane: low halves, odd lane: high halves
+};
+
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v)
+{
+    // quad_perm:[1,0,3,2]: every lane reads its pair partner
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// one half of rol64(own : partner, R)
+template <int R>
+__device__ __forceinline__ uint32_t rol64_half(uint32_t own, uint32_t partner)
+{
+    static_assert(R > 0 && R < 64 && R != 32, "the rho offsets of Keccak-f[1600] other than 0");
+    if constexpr (R < 32)
+        return __builtin_amdgcn_alignbit(own, partner, 32 - R);
+    else
+        return __builtin_amdgcn_alignbit(partner, own, 64 - R);
+}
+
+#define SEAMD_RHOPI_HALF(SRC, DST, R)                                     {                                                                         const uint32_t t_ = s.w[SRC] ^ d[(SRC) % 5];                          if constexpr ((R) == 0)                                                   b[DST] = t_;                                                      else                                                                      b[DST] = rol64_half<((R) == 0 ? 1 : (R))>(t_, pair_swap(t_));     }
+
+// rc = this lane's half of the round constant
+__device__ __forceinline__ void keccak_half_round(KeccakHalf &s, uint32_t rc)
+{
+    uint32_t c[5], d[5], b[25];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = xor3(xor3(s.w[x], s.w[x + 5], s.w[x + 10]), s.w[x + 15], s.w[x + 20]);
+#pragma unroll
+    for (int x = 0; x < 5; x++)
+    {
+        const uint32_t cn = c[(x + 1) % 5];
+        d[x]              = c[(x + 4) % 5] ^ rol64_half<1>(cn, pair_swap(cn));
+    }
+    SEAMD_RHOPI_HALF(0, 0, 0);
+    SEAMD_RHOPI_HALF(1, 10, 1);
+    SEAMD_RHOPI_HALF(2, 20, 62);
+    SEAMD_RHOPI_HALF(3, 5, 28);
+    SEAMD_RHOPI_HALF(4, 15, 27);
+    SEAMD_RHOPI_HALF(5, 16, 36);
+    SEAMD_RHOPI_HALF(6, 1, 44);
+    SEAMD_RHOPI_HALF(7, 11, 6);
+    SEAMD_RHOPI_HALF(8, 21, 55);
+    SEAMD_RHOPI_HALF(9, 6, 20);
+    SEAMD_RHOPI_HALF(10, 7, 3);
+    SEAMD_RHOPI_HALF(11, 17, 10);
+    SEAMD_RHOPI_HALF(12, 2, 43);
+    SEAMD_RHOPI_HALF(13, 12, 25);
+    SEAMD_RHOPI_HALF(14, 22, 39);
+    SEAMD_RHOPI_HALF(15, 23, 41);
+    SEAMD_RHOPI_HALF(16, 8, 45);
+    SEAMD_RHOPI_HALF(17, 18, 15);
+    SEAMD_RHOPI_HALF(18, 3, 21);
+    SEAMD_RHOPI_HALF(19, 13, 8);
+    SEAMD_RHOPI_HALF(20, 14, 18);
+    SEAMD_RHOPI_HALF(21, 24, 2);
+    SEAMD_RHOPI_HALF(22, 9, 61);
+    SEAMD_RHOPI_HALF(23, 19, 56);
+    SEAMD_RHOPI_HALF(24, 4, 14);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5)
+    {
+#pragma unroll
+        for (int x = 0; x < 5; x++) s.w[y + x] = chi3(b[y + x], b[y + (x + 1) % 5], b[y + (x + 2) % 5]);
+    }
+    s.w[0] ^= rc;
+}
+#undef SEAMD_RHOPI_HALF
+
+// `part` = 0 on the even lane (low halves), 1 on the odd lane (high halves)
+__device__ __forceinline__ void keccak_half_f1600(KeccakHalf &s, uint32_t part)
+{
+#pragma unroll 2
+    for (int r = 0; r < 24; r++) keccak_half_round(s, part ? kKeccakRC[r][1] : kKeccakRC[r][0]);
+}
+
+// this lane's half of the state prng_absorb() builds (seed[64] || le64(ctr), SHAKE256 padding)
+__device__ __forceinline__ void prng_absorb_half(KeccakHalf &s, const uint32_t (&seed)[16], uint64_t ctr,
+                                                 uint32_t part)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.w[i] = part ? seed[2 * i + 1] : seed[2 * i];
+    s.w[8] = part ? (uint32_t)(ctr >> 32) : (uint32_t)ctr;
+    s.w[9] = part ? 0u : 0x1Fu;
+#pragma unroll
+    for (int i = 10; i < 25; i++) s.w[i] = 0;
+    s.w[16] = part ? 0x80000000u : 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-cooperative form: ONE state over the 64 lanes of a wave -- the latency form for a handful of chains.
+//
+// State lane (x, y) lives in wave lane 8 y + x + 1 ("primary"), as (lo, hi) in two VGPRs: plane y occupies an
+// 8-lane group, two planes per 16-lane DPP row, planes 0..4 = lanes 0..39, the rest of the wave holds zeros.
+// Each group is [4' 0 1 2 3 4 0' 1']: lane 0 is a copy of column 4, lanes 6, 7 copies of columns 0, 1, so that
+// the in-plane neighbours x-1, x+1, x+2 of every primary lane are plain DPP row shifts (no wrap handling
+// except C[x+1] of column 4, taken from 4 lanes to the left).  Per round:
+//   theta  parity over the planes: v_xor_dpp row_ror:8 (the two planes of a row), then v_permlane16_swap and
+//          v_permlane32_swap (gfx950) fold the rows: 7 instructions per half, no LDS;
+//          D = C[x-1] ^ rol1(C[x+1]) with row_shr:1 / row_shl:1; A ^= D & valid (one v_bitop3)
+//   rho    one 64-bit rotation by a per-lane amount: 2 v_cndmask (halves swapped for R >= 32) + 2 v_alignbit
+//   pi     one ds_bpermute_b32 per half (a fixed permutation; it also refreshes the copy lanes)
+//   chi    B[x+1], B[x+2] by row_shl:1 / row_shl:2, one v_bitop3 per half;  iota on the lane of (0, 0)
+// About 40 instructions per round instead of 190: a permutation takes ~3 us instead of ~9-10 us of a lone
+// wave, at 13x the work per state -- for launches of at most a few waves per SIMD (a single se_encrypt call,
+// batches of up to ~2 000 ciphertexts incl. the virtual ones of the prime speculation).
+// ------------------------------------------------------------------------------------------
+struct WaveKeccak
+{
+    uint32_t lo, hi;      // this lane's state lane (or copy, or zero)
+    // per-lane constants (set up once per kernel by wave_keccak_init)
+    uint32_t sh;          // rho: v_alignbit amount
+    uint32_t pi_addr;     // pi: 4 * source lane for ds_bpermute
+    uint32_t valid;       // all-ones on lanes of planes 0..4
+    uint32_t iota;        // all-ones on the primary lane of state lane (0, 0)
+    bool swap;            // rho: rotation amount >= 32 (or == 0): halves swapped first
+    bool col4;            // primary lane of column 4: C[x+1] comes from lane - 4
+    int index;            // x + 5 y on primary lanes of planes 0..4, -1 elsewhere
+};
+
+__device__ __constant__ const uint8_t kKeccakRho[25] = {0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3,  10, 43,
+                                                        25, 39, 41, 45, 15, 21, 8,  18, 2,  61, 56, 14};
+
+__device__ __forceinline__ void wave_keccak_init(WaveKeccak &k, int lane)
+{
+    const int g = lane & 7, y = lane >> 3;
+    const int x = (g + 4) % 5;
+    const bool in_state = y < 5;
+    const bool primary  = in_state && g >= 1 && g <= 5;
+    k.index = primary ? x + 5 * y : -1;
+    k.valid = in_state ? 0xFFFFFFFFu : 0u;
+    k.iota  = (lane == 1) ? 0xFFFFFFFFu : 0u;
+    k.col4  = g == 5;
+    const int R = in_state ? kKeccakRho[x + 5 * y] : 0;
+    // rol64 by R on (lo, hi): for R in 1..31 lo' = alignbit(lo, hi, 32 - R), hi' = alignbit(hi, lo, 32 - R);
+    // for R >= 32 the same on swapped halves with R - 32; R == 0 is "swapped, amount 0" (alignbit by 0 yields
+    // its second source)
+    k.swap = (R >= 32) || (R == 0);
+    k.sh   = (uint32_t)((32 - (R & 31)) & 31);
+    // pi: B[x'][y'] = rol(A[x][y]) with x' = y, y' = 2x + 3y  =>  this lane (x', y') pulls from the primary lane of
+    // x = 3 y' + x' (mod 5), y = x'
+    const int xs = (3 * y + x) % 5, ys = x;
+    k.pi_addr = in_state ? (uint32_t)(4 * (8 * ys + xs + 1)) : (uint32_t)(4 * lane);
+    k.lo = k.hi = 0;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
+// xor over the five planes of every column, valid on every lane of planes 0..4 (and beyond)
+__device__ __forceinline__ uint32_t wave_column_parity(uint32_t v)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    uint32_t t = v ^ dpp_row<0x128>(v);                               // row_ror:8: the two planes of a row
+    u2 r       = __builtin_amdgcn_permlane16_swap(t, t, false, false);  // {rows 0,0,2,2 ; rows 1,1,3,3}
+    t          = r.x ^ r.y;                                             // rows 0^1 and 2^3
+    r          = __builtin_amdgcn_permlane32_swap(t, t, false, false);  // {lower, lower ; upper, upper}
+    return r.x ^ r.y;
+}
+
+__device__ __forceinline__ void wave_keccak_round(WaveKeccak &k, uint32_t rclo, uint32_t rchi)
+{
+    // theta
+    const uint32_t clo = wave_column_parity(k.lo), chi_ = wave_column_parity(k.hi);
+    // C[x+1]: lane + 1, or lane - 4 for column 4 (both fetched unconditionally: a DPP move under a
+    // lane-dependent condition would be compiled into an exec-masked branch)
+    const uint32_t plo_a = dpp_row<0x101>(clo), plo_b = dpp_row<0x114>(clo);
+    const uint32_t phi_a = dpp_row<0x101>(chi_), phi_b = dpp_row<0x114>(chi_);
+    const uint32_t plo = k.col4 ? plo_b : plo_a, phi = k.col4 ? phi_b : phi_a;
+    const uint32_t dlo = dpp_row<0x111>(clo) ^ __builtin_amdgcn_alignbit(plo, phi, 31);   // C[x-1] ^ rol1(C[x+1])
+    const uint32_t dhi = dpp_row<0x111>(chi_) ^ __builtin_amdgcn_alignbit(phi, plo, 31);
+    uint32_t alo = __builtin_amdgcn_bitop3_b32(k.lo, dlo, k.valid, 0x78);   // a ^ (b & c)
+    uint32_t ahi = __builtin_amdgcn_bitop3_b32(k.hi, dhi, k.valid, 0x78);
+    // rho
+    const uint32_t a = k.swap ? ahi : alo, b = k.swap ? alo : ahi;
+    const uint32_t rlo = __builtin_amdgcn_alignbit(a, b, k.sh), rhi = __builtin_amdgcn_alignbit(b, a, k.sh);
+    // pi
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)k.pi_addr, (int)rlo);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)k.pi_addr, (int)rhi);
+    // chi, iota
+    k.lo = chi3(blo, dpp_row<0x101>(blo), dpp_row<0x102>(blo));
+    k.hi = chi3(bhi, dpp_row<0x101>(bhi), dpp_row<0x102>(bhi));
+    k.lo = __builtin_amdgcn_bitop3_b32(k.lo, k.iota, rclo, 0x78);
+    k.hi = __builtin_amdgcn_bitop3_b32(k.hi, k.iota, rchi, 0x78);
+}
+
+__device__ __forceinline__ void wave_keccak_f1600(WaveKeccak &k)
+{
+#pragma unroll 2
+    for (int r = 0; r < 24; r++) wave_keccak_round(k, kKeccakRC[r][0], kKeccakRC[r][1]);
+}
+
+// The state prng_absorb() builds (seed[64] || le64(ctr), SHAKE256 padding), spread over the wave: `seed`
+// points at the 64 seed bytes in global memory.
+__device__ __forceinline__ void wave_prng_absorb(WaveKeccak &k, const uint8_t *seed, uint64_t ctr, int lane)
+{
+    const int g = lane & 7, y = lane >> 3;
+    const int i = (y < 5) ? ((g + 4) % 5) + 5 * y : 25;   // state lane this wave lane holds (copies included)
+    uint32_t lo = 0, hi = 0;
+    if (i < 8)
+    {
+        const uint2 v = *reinterpret_cast<const uint2 *>(seed + 8 * i);
+        lo = v.x, hi = v.y;
+    }
+    else if (i == 8)
+        lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+    else if (i == 9)
+        lo = 0x1Fu;
+    else if (i == 16)
+        hi = 0x80000000u;
+    k.lo = lo, k.hi = hi;
+}
+
 }  // namespace seamd

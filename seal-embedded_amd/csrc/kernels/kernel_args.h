@@ -47,7 +47,14 @@ struct UniformArgs
     uint32_t helper_fill;  // waves per workgroup that small batches are filled up to with helpers
                            // (0 = default 8 = two per SIMD; 4 leaves room for a co-resident
                            // 1024-thread transform workgroup at n = 16384)
+    const uint8_t *prime_of;  // optional [B]: ciphertext b samples ONLY prime prime_of[b], into output row b
+                              // (out_primes = 1; prime_lo / prime_hi / out_prime_base are ignored): the virtual
+                              // ciphertexts of ALL guessed primes of the prime speculation in ONE launch
 };
+// Launches of at most this many ciphertexts take the wave-per-ciphertext kernel (k_sample_uniform_wave):
+// 16 waves per CU = 4 per SIMD, where its ~7.8 us per permutation still beats the lane form's 8.6-10.7 us
+// (tools/ubench5).
+inline size_t uniform_wave_limit(unsigned num_cus) { return (size_t)16 * (num_cus ? num_cus : 256u); }
 struct CbdArgs
 {
     const uint8_t *seeds;
@@ -95,7 +102,7 @@ struct SpecPlan
     uint32_t total;                // virtual ciphertexts in all
 };
 hipError_t launch_spec_setup(const SpecPlan &, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v,
-                             hipStream_t);
+                             uint8_t *prime_v, hipStream_t);
 hipError_t launch_spec_select(const SpecPlan &, uint32_t n, uint64_t *ctr0, const uint64_t *ctrout_v,
                               const uint32_t *rows, uint32_t *c1, uint32_t *fail, hipStream_t);
 

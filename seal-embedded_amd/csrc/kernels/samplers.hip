@@ -63,7 +63,10 @@ constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid
 // MAXT: the largest workgroup the instantiation is launched with.  Up to 8 waves per workgroup (every
 // batch <= 4 x 64 x CUs, i.e. all BASELINE shapes) the kernel may use 256 VGPRs: 160, no spills; the
 // 1024-thread form is capped at 128 and spills 140 B per lane (uniform stage 6.28 -> 6.11 ms at C2).
-template <int LOGN, int MAXT>
+// LANE_PRIME: UniformArgs::prime_of is honoured (one prime per ciphertext, chosen per lane) -- an instantiation
+// of its own so that the per-lane modulus constants cost the batch kernels nothing (166 vs 160 VGPRs, +1.5 %
+// on the dominant kernel of C2 when it was a run-time branch).
+template <int LOGN, int MAXT, bool LANE_PRIME = false>
 __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArgs A)
 {
     constexpr int N          = 1 << LOGN;
@@ -106,10 +109,14 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
         for (int i = 0; i < 16; i++) lds_seed[threadIdx.x * 16 + i] = seed[i];
     }
 
-    for (uint32_t j = A.prime_lo; j < A.prime_hi; j++)
+    // prime_of: one prime per ciphertext, chosen per LANE (the modulus constants become lane values; the loop
+    // runs once for the whole workgroup, so its barriers stay uniform)
+    const uint32_t j_first = LANE_PRIME ? 0u : A.prime_lo, j_end = LANE_PRIME ? 1u : A.prime_hi;
+    for (uint32_t jl = j_first; jl < j_end; jl++)
     {
+        const uint32_t j = LANE_PRIME ? (uint32_t)A.prime_of[b] : jl;
         const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
-        uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+        uint32_t *mypoly = A.out + (LANE_PRIME ? b : b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
 
         uint32_t nrej = 0;
         const uint64_t bulk_ctr = ctr;   // the 4n-byte block; redraw candidates follow at ctr + 1 ..
@@ -437,6 +444,170 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
 }
 
 // ------------------------------------------------------------------------------------------
+// The same sampler for a HANDFUL of ciphertexts: one WAVE per ciphertext (keccak.cuh, WaveKeccak).
+//
+// The bulk block of a polynomial is one sequential sponge squeeze (121 permutations at n = 4096, 482 at
+// n = 16384); a lane-per-ciphertext kernel spends ~10 us per permutation on it however few ciphertexts there
+// are, which is all a single se_encrypt call consists of ("single calls").  Here the 64
+// lanes of a wave share ONE state (~3.2 us per permutation measured, tools/ubench5), the 17 lanes that hold the
+// rate words reduce / test / store their own two words (one 136-byte contiguous store per step), rejected
+// positions are ranked with ballots, and the redraws -- independent SHAKE calls -- are 64 candidates per round,
+// one per lane in the ordinary lane-per-state form, consumed in counter order exactly as sample.c:50-56 does
+// (the k-th rejected coefficient takes the k-th accepted candidate; a candidate is drawn only while one is
+// needed).  13x the instructions per state of the lane form: used for launches of at most a few waves per
+// SIMD (launch_sample_uniform), i.e. single calls, the virtual ciphertexts of the prime speculation, small
+// batches.  Same outputs, same end counters, same reject-list / marker conventions as k_sample_uniform.
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_sample_uniform_wave(DevParams P, UniformArgs A)
+{
+    constexpr int N          = 1 << LOGN;
+    constexpr int FULL_STEPS = (N * 4) / 136;
+    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;
+    static_assert(TAIL_WORDS % 2 == 0 && TAIL_WORDS <= 32, "the tail is a whole number of state lanes");
+
+    const int lane  = threadIdx.x & 63;
+    const size_t bq = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // wave-uniform: a wave without a ciphertext (or masked out of a redo launch) has nothing to do
+    if (bq >= A.B) return;
+    if (A.only_from && !(A.only_from[bq] != 0 && A.prime_lo >= A.only_from[bq])) return;
+    const size_t b = bq;
+
+    uint32_t seed[16];   // every lane: the lane-per-state candidates of the redraw phase need all of it
+    load_seed(seed, A.seeds, b);
+    const uint8_t *seedp = A.seeds + b * kSeedBytes;
+    uint64_t ctr         = A.ctr_in ? A.ctr_in[b] : 0;
+    uint32_t *mylist     = A.rej_list + b * A.rej_cap;
+    const uint64_t lt    = (1ull << lane) - 1ull;   // lanes below this one
+
+    WaveKeccak wk;
+    wave_keccak_init(wk, lane);
+
+    const uint32_t j_first = A.prime_of ? (uint32_t)A.prime_of[b] : A.prime_lo;   // wave-uniform
+    const uint32_t j_end   = A.prime_of ? j_first + 1u : A.prime_hi;
+    for (uint32_t j = j_first; j < j_end; j++)
+    {
+        const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
+        uint32_t *mypoly = A.out + (A.prime_of ? b : b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+        wave_prng_absorb(wk, seedp, ctr, lane);
+        ctr++;
+        uint32_t nrej = 0;   // wave-uniform
+
+        // one squeeze step: the lanes holding state lanes 0 .. words/2 - 1 emit two words each
+        auto emit = [&](uint32_t idx, int words) {
+            const bool mine = wk.index >= 0 && 2 * wk.index < words;
+            const bool r0 = mine && wk.lo >= bound, r1 = mine && wk.hi >= bound;
+            if (mine)
+            {
+                const uint32_t w0 = r0 ? kRejMarker : barrett32(wk.lo, q, crh);
+                const uint32_t w1 = r1 ? kRejMarker : barrett32(wk.hi, q, crh);
+                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * wk.index) = make_uint2(w0, w1);
+            }
+            const uint64_t m0 = __ballot(r0), m1 = __ballot(r1);
+            if ((m0 | m1) != 0)
+            {
+                // primary lanes ascend with the state-lane index, and a lane's low word precedes its high
+                // word: the rank of a rejected word in position order
+                const uint32_t before = nrej + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt);
+                if (r0 && before < A.rej_cap) mylist[before] = idx + 2 * wk.index;
+                if (r1 && before + (r0 ? 1u : 0u) < A.rej_cap) mylist[before + (r0 ? 1u : 0u)] = idx + 2 * wk.index + 1;
+                nrej += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+            }
+        };
+        uint32_t idx = 0;
+        for (int step = 0; step < FULL_STEPS; step++)
+        {
+            wave_keccak_f1600(wk);
+            emit(idx, 34);
+            idx += 34;
+        }
+        if constexpr (TAIL_WORDS > 0)
+        {
+            wave_keccak_f1600(wk);
+            emit(idx, TAIL_WORDS);
+        }
+        // bulk stores and list entries must have landed before other lanes patch / read them
+        __builtin_amdgcn_s_waitcnt(0);
+        __threadfence_block();
+
+        // ---- redraws: 64 candidates block(ctr + lane)[0:4] per round -------------------------------
+        uint32_t need    = (A.debug_flags & 2) ? 0u : nrej;
+        uint32_t done    = 0;                       // rejected coefficients resolved so far
+        uint32_t scanpos = 0;                       // list-overflow form: next index to scan for a marker
+        const bool by_list = nrej <= A.rej_cap;     // else: the rejected positions are the marker words
+        while (need > 0)
+        {
+            KeccakState cs;
+            prng_absorb(cs, seed, ctr + (uint64_t)lane);
+            keccak_f1600_fresh(cs);                 // only cs.lo[0] is consumed
+            const uint32_t x   = cs.lo[0];
+            const bool acc     = x < bound;
+            const uint64_t am  = __ballot(acc);
+            const uint32_t pre = (uint32_t)__popcll(am & lt);      // accepted candidates before this one
+            const bool take    = acc && pre < need;                 // drawn (pre < need) and accepted
+            const uint32_t val = barrett32(x, q, crh);
+            if (by_list)
+            {
+                if (take)
+                {
+                    const uint32_t pos =
+                        __hip_atomic_load(mylist + done + pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mypoly[pos] = val;
+                }
+            }
+            else
+            {
+                // rare (more rejections than list entries): the accepted candidates one by one, each to the
+                // next marker word found by a wave-wide scan
+                uint64_t tm = __ballot(take);
+                while (tm != 0)
+                {
+                    const int src = __builtin_ctzll(tm);
+                    tm &= tm - 1;
+                    const uint32_t v = (uint32_t)__shfl((int)val, src);
+                    for (;;)
+                    {
+                        const uint32_t p  = scanpos + (uint32_t)lane;
+                        const uint32_t c  = p < (uint32_t)N
+                                                ? __hip_atomic_load(mypoly + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                : 0u;
+                        const uint64_t mk = __ballot(p < (uint32_t)N && c == kRejMarker);
+                        if (mk != 0)
+                        {
+                            const uint32_t hit = scanpos + (uint32_t)__builtin_ctzll(mk);
+                            if (lane == 0) mypoly[hit] = v;
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __threadfence_block();
+                            scanpos = hit + 1;
+                            break;
+                        }
+                        scanpos += 64;
+                        if (scanpos >= (uint32_t)N) break;   // cannot happen: `need` markers are left
+                    }
+                }
+            }
+            const uint32_t got = (uint32_t)__popcll(am);
+            if (got >= need)
+            {
+                // the need-th accepted candidate ends the draws: everything up to it was consumed
+                const uint64_t last = __ballot(acc && pre == need - 1);
+                ctr += (uint64_t)__builtin_ctzll(last) + 1;
+                done += need;
+                need = 0;
+            }
+            else
+            {
+                ctr += 64;
+                done += got;
+                need -= got;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
+}
+
+// ------------------------------------------------------------------------------------------
 // Centered binomial error (k = 21): one 96-byte block -> 16 int8 coefficients per thread.
 // counter = ctr_base[b] (or 0) + ctr_offset + block index.  Output int8 [B][blocks*16].
 // ------------------------------------------------------------------------------------------
@@ -625,9 +796,33 @@ static void chain_geometry(size_t B, unsigned num_cus, unsigned &threads, unsign
     if (master_waves) *master_waves = (unsigned)w;
 }
 
+template <int LOGN>
+static hipError_t launch_uniform_wave(const DevParams &P, const UniformArgs &A, hipStream_t st)
+{
+    const unsigned waves_per_wg = 4;   // one per SIMD of the CU a workgroup lands on
+    hipLaunchKernelGGL((k_sample_uniform_wave<LOGN>), dim3((A.B + waves_per_wg - 1) / waves_per_wg),
+                       dim3(64 * waves_per_wg), 0, st, P, A);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipStream_t st)
 {
     if (A0.B == 0) return hipSuccess;
+    // A handful of chains: one wave per ciphertext (2.2-2.7x shorter chains up to one wave per SIMD, break-even
+    // near 4 per SIMD -- tools/ubench5).  debug_flags 32 / 64 force the lane / the wave form (tests).
+    if (((A0.B <= uniform_wave_limit(P.num_cus) && !(A0.debug_flags & 32)) || (A0.debug_flags & 64)) &&
+        !(A0.debug_flags & (1 | 4)))
+    {
+        switch (P.logn)
+        {
+            case 10: return launch_uniform_wave<10>(P, A0, st);
+            case 11: return launch_uniform_wave<11>(P, A0, st);
+            case 12: return launch_uniform_wave<12>(P, A0, st);
+            case 13: return launch_uniform_wave<13>(P, A0, st);
+            case 14: return launch_uniform_wave<14>(P, A0, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     unsigned threads, grid_x, mw;
     size_t lds;
     chain_geometry(A0.B, P.num_cus, threads, grid_x, lds, &mw, !(A0.debug_flags & 8),
@@ -635,13 +830,21 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
     UniformArgs A   = A0;
     A.master_waves  = mw;
     if (A.debug_flags & 16) A.spec = nullptr;  // A/B: helper waves without speculation
+    // the per-lane-prime form exists for workgroups of up to 8 waves (every speculation launch: <= 65 536
+    // virtual ciphertexts, small_limit)
+    if (A.prime_of && threads > 512) return hipErrorInvalidValue;
     dim3 grid(grid_x), block(threads);
 #define SEAMD_LAUNCH_UNIFORM_T(L, T)                                                             \
     (void)hipFuncSetAttribute((const void *)k_sample_uniform<L, T>,                              \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
     hipLaunchKernelGGL((k_sample_uniform<L, T>), grid, block, lds, st, P, A)
+#define SEAMD_LAUNCH_UNIFORM_P(L)                                                                \
+    (void)hipFuncSetAttribute((const void *)k_sample_uniform<L, 512, true>,                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL((k_sample_uniform<L, 512, true>), grid, block, lds, st, P, A)
 #define SEAMD_LAUNCH_UNIFORM(L)                                                                  \
-    if (threads > 512) { SEAMD_LAUNCH_UNIFORM_T(L, 1024); } else { SEAMD_LAUNCH_UNIFORM_T(L, 512); }
+    if (A.prime_of) { SEAMD_LAUNCH_UNIFORM_P(L); }                                               \
+    else if (threads > 512) { SEAMD_LAUNCH_UNIFORM_T(L, 1024); } else { SEAMD_LAUNCH_UNIFORM_T(L, 512); }
     switch (P.logn)
     {
         case 10: SEAMD_LAUNCH_UNIFORM(10); break;
@@ -652,6 +855,7 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
         default: return hipErrorInvalidValue;
     }
 #undef SEAMD_LAUNCH_UNIFORM
+#undef SEAMD_LAUNCH_UNIFORM_P
 #undef SEAMD_LAUNCH_UNIFORM_T
     return hipGetLastError();
 }
@@ -698,7 +902,8 @@ hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
 // ciphertexts (UniformArgs::only_from), which normally finds nothing to do.  Idle lanes are free in a one-ciphertext call; the latency drops from np
 // squeezes to one.
 // ------------------------------------------------------------------------------------------
-__global__ void k_spec_setup(SpecPlan S, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v)
+__global__ void k_spec_setup(SpecPlan S, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v,
+                             uint8_t *prime_v)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= S.total) return;
@@ -710,7 +915,8 @@ __global__ void k_spec_setup(SpecPlan S, const uint8_t *seeds, uint8_t *seeds_v,
     uint4 *dst       = reinterpret_cast<uint4 *>(seeds_v + (size_t)v * kSeedBytes);
 #pragma unroll
     for (int i = 0; i < 4; i++) dst[i] = src[i];
-    ctr_v[v] = S.base[j] + g;
+    ctr_v[v]   = S.base[j] + g;
+    prime_v[v] = (uint8_t)j;
 }
 
 // one workgroup per real ciphertext: follow the counter chain through the guesses and copy the
@@ -748,10 +954,11 @@ __global__ __launch_bounds__(256) void k_spec_select(SpecPlan S, uint32_t n, uin
 }
 
 hipError_t launch_spec_setup(const SpecPlan &S, const uint8_t *seeds, uint8_t *seeds_v, uint64_t *ctr_v,
-                             hipStream_t st)
+                             uint8_t *prime_v, hipStream_t st)
 {
     if (S.total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_spec_setup, dim3((S.total + 255) / 256), dim3(256), 0, st, S, seeds, seeds_v, ctr_v);
+    hipLaunchKernelGGL(k_spec_setup, dim3((S.total + 255) / 256), dim3(256), 0, st, S, seeds, seeds_v, ctr_v,
+                       prime_v);
     return hipGetLastError();
 }
 

@@ -72,11 +72,10 @@ Context::~Context()
     if (ev_done) (void)hipEventDestroy(ev_done);
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
-    for (auto &sp : sp_streams)
-        if (sp && sp != aux_stream) (void)hipStreamDestroy(sp);
+    if (spec_stream) (void)hipStreamDestroy(spec_stream);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
                     d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general, d_compact,
-                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail};
+                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail, d_sp_prime};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -574,7 +573,7 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
     {
         // a handful of ciphertexts: latency path (all primes' samplers at once, prime speculation)
         SpecPlan plan;
-        if (split_mode == 2 && small_batch_plan(B, plan))
+        if (split_mode == 2 && small_batch_plan(B, plan) && speculation_pays(B, plan))
             return encrypt_sym_small(plan, d_values, d_share_seeds, d_seeds, d_c0, d_c1, d_ntt_pte, d_pte,
                                      d_status, st);
     }
@@ -714,6 +713,26 @@ bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
     return true;
 }
 
+// Which form serves a small batch faster?  The uniform sampler is a chain of `steps` sequential permutations
+// per polynomial; what it costs depends on the kernel form the launch takes (kernels/samplers.hip,
+// launch_sample_uniform; per-permutation times measured with tools/ubench5 and tools/chain_step_probe.py):
+//   wave per ciphertext : 3.3 us up to 256 waves, + 1.2 us per further 1 024 waves (4.2 us at one wave per
+//                         SIMD, 7.8 us at four)
+//   lane per ciphertext : 10.7 us whatever the batch (up to one wave per SIMD)
+// Speculation runs the guesses of every prime at once: one chain deep, but B + plan.total ciphertexts wide;
+// the plain form runs np chains in sequence, B wide.
+bool Context::speculation_pays(size_t B, const SpecPlan &plan) const
+{
+    const double steps = (double)((hp.n * 4 + 135) / 136);
+    auto perm_us = [&](size_t cts) {
+        if (cts > uniform_wave_limit((unsigned)num_cus) || (debug_flags & 32)) return 10.7;
+        return 3.3 + 1.2 * (cts > 256 ? (double)(cts - 256) / 1024.0 : 0.0);
+    };
+    const double spec  = steps * perm_us(B + plan.total);
+    const double plain = (double)hp.nprimes * steps * perm_us(B);
+    return spec < 0.9 * plain;
+}
+
 int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, const uint8_t *d_share_seeds,
                                const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1,
                                uint32_t *d_ntt_pte, int64_t *d_pte, uint8_t *d_status, hipStream_t st)
@@ -728,15 +747,16 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
     if (total > sp_cap)
     {
         SEAMD_HIP(hipDeviceSynchronize());
-        void *old[] = {d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows};
+        void *old[] = {d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_prime};
         for (void *p : old)
             if (p) (void)hipFree(p);
-        d_sp_seeds = nullptr, d_sp_ctr = nullptr, d_sp_ctrout = nullptr, d_sp_rows = nullptr;
+        d_sp_seeds = nullptr, d_sp_ctr = nullptr, d_sp_ctrout = nullptr, d_sp_rows = nullptr, d_sp_prime = nullptr;
         sp_cap = 0;
         SEAMD_HIP(hipMalloc((void **)&d_sp_seeds, total * 64));
         SEAMD_HIP(hipMalloc((void **)&d_sp_ctr, total * sizeof(uint64_t)));
         SEAMD_HIP(hipMalloc((void **)&d_sp_ctrout, total * sizeof(uint64_t)));
         SEAMD_HIP(hipMalloc((void **)&d_sp_rows, total * (size_t)n * sizeof(uint32_t)));
+        SEAMD_HIP(hipMalloc((void **)&d_sp_prime, total));
         sp_cap = total;
     }
     if (B > sp_fail_cap)
@@ -747,22 +767,29 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
         SEAMD_HIP(hipMalloc((void **)&d_sp_fail, 1024 * sizeof(uint32_t)));
         sp_fail_cap = 1024;
     }
-    // prime 1 rides on the auxiliary stream behind the (tiny) cbd / encode kernels: with the runtime's
-    // default of 4 hardware queues a 3-prime call then has a queue per concurrent launch
-    sp_streams[1] = aux_stream;
-    for (uint32_t j = 2; j < np; j++)
-        if (!sp_streams[j]) SEAMD_HIP(hipStreamCreateWithFlags(&sp_streams[j], hipStreamNonBlocking));
+    // Three streams whatever the length of the prime chain (the runtime's default of 4 hardware queues is
+    // enough): the guesses of ALL primes are ONE launch (UniformArgs::prime_of).
+    if (!spec_stream) SEAMD_HIP(hipStreamCreateWithFlags(&spec_stream, hipStreamNonBlocking));
 
     CbdArgs ca{d_seeds, nullptr, d_err, n / 16, (uint32_t)B};
     EncArgs ea{d_values, d_err, nullptr, d_c0, d_c1, d_ntt_pte, d_pte, d_status, d_general, d_compact};
 
-    //   S   : U_0 (real ciphertexts) ───────────────┐ (wait all) select ► (wait A) N_0 .. N_{np-1}
-    //   A   : cbd ► k_encode_rns ───────────────────┤
-    //         └► setup ► U_1 (guesses) ─────────────┤
-    //   P_j :        (wait setup) U_j (guesses) ────┘   (j >= 2)
+    //   S : U_0 (real ciphertexts) ─────────────────────┐ (wait P) select ► redo (masked) ► (wait A) N_0 .. N_{np-1}
+    //   A : cbd ► k_encode_rns ─────────────────────────┤
+    //   P : setup ► U_{1..np-1} (all guesses, one launch)┘
     SEAMD_HIP(hipEventRecord(ev_fork, st));
     SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
-    for (uint32_t j = 2; j < np; j++) SEAMD_HIP(hipStreamWaitEvent(sp_streams[j], ev_fork, 0));
+    SEAMD_HIP(hipStreamWaitEvent(spec_stream, ev_fork, 0));
+
+    SEAMD_HIP(launch_spec_setup(plan, d_share_seeds, d_sp_seeds, d_sp_ctr, d_sp_prime, spec_stream));
+    {
+        // one output row per virtual ciphertext; its prime comes from d_sp_prime
+        UniformArgs ug{d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_rej + B * rej_cap, rej_cap, (uint32_t)total,
+                       0,          0,        1,           d_spec + B * spec_cap, spec_cap, 0, debug_flags,
+                       nullptr,    0,        0,           d_sp_prime};
+        SEAMD_HIP(launch_sample_uniform(dp, ug, spec_stream));
+        SEAMD_HIP(hipEventRecord(ev_enc, spec_stream));
+    }
 
     stage_begin(0, aux_stream);
     SEAMD_HIP(launch_sample_cbd(ca, aux_stream));
@@ -772,41 +799,12 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
     stage_end(aux_stream);
     SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
 
-    SEAMD_HIP(launch_spec_setup(plan, d_share_seeds, d_sp_seeds, d_sp_ctr, sp_streams[1]));
-    SEAMD_HIP(hipEventRecord(ev_enc, sp_streams[1]));
-
     UniformArgs u0{d_share_seeds, nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, 1, np,
                    d_spec,        spec_cap, 0,     debug_flags};
     stage_begin(1, st);
     SEAMD_HIP(launch_sample_uniform(dp, u0, st));
     stage_end(st);
-
-    for (uint32_t j = 1; j < np; j++)
-    {
-        hipStream_t sj = sp_streams[j];
-        if (j > 1) SEAMD_HIP(hipStreamWaitEvent(sj, ev_enc, 0));
-        const size_t off = plan.offset[j], cnt = B * plan.count[j];
-        // one output row per virtual ciphertext: out_primes = 1, rows counted from prime j
-        UniformArgs uj{d_sp_seeds + off * 64,
-                       d_sp_ctr + off,
-                       d_sp_ctrout + off,
-                       d_sp_rows + off * n,
-                       d_rej + (B + off) * rej_cap,
-                       rej_cap,
-                       (uint32_t)cnt,
-                       j,
-                       j + 1,
-                       1,
-                       d_spec + (B + off) * spec_cap,
-                       spec_cap,
-                       0,
-                       debug_flags,
-                       nullptr,
-                       j};
-        SEAMD_HIP(launch_sample_uniform(dp, uj, sj));
-        SEAMD_HIP(hipEventRecord(ev_prime[j], sj));
-        SEAMD_HIP(hipStreamWaitEvent(st, ev_prime[j], 0));
-    }
+    SEAMD_HIP(hipStreamWaitEvent(st, ev_enc, 0));
     SEAMD_HIP(launch_spec_select(plan, n, d_ctr, d_sp_ctrout, d_sp_rows, d_c1, d_sp_fail, st));
     // misses (~1e-7 per prime): the ordinary per-prime chain, masked to the ciphertexts that missed;
     // without a miss every workgroup of these launches returns at once

@@ -63,12 +63,13 @@ struct Context
     uint64_t *d_sp_ctr    = nullptr;  // [sp_cap] guessed start counters
     uint64_t *d_sp_ctrout = nullptr;  // [sp_cap] end counters under each guess
     uint32_t *d_sp_rows   = nullptr;  // [sp_cap][n] a_j under each guess
+    uint8_t *d_sp_prime   = nullptr;  // [sp_cap] prime of each virtual ciphertext
     uint32_t *d_sp_fail   = nullptr;  // [sp_fail_cap] 0 = chain resolved, j = window of prime j missed
     size_t sp_cap = 0, sp_fail_cap = 0;
     uint32_t small_limit = getenv("SE_AMD_SMALL_LIMIT") ? (uint32_t)atoi(getenv("SE_AMD_SMALL_LIMIT")) : 65536;  // virtual ciphertexts a small call may fan out to
     // ... and the bytes their output rows may take (one n-word row per virtual ciphertext)
     size_t small_bytes = getenv("SE_AMD_SMALL_BYTES") ? (size_t)atoll(getenv("SE_AMD_SMALL_BYTES")) : ((size_t)1 << 30);
-    hipStream_t sp_streams[kMaxPrimes] = {};
+    hipStream_t spec_stream = nullptr;   // the guesses of ALL primes run as one launch on it
     uint8_t *d_compact  = nullptr;  // [scratch_cap] k_encode_rns -> k_ntt_fuse: plaintext b travels as one int32 row
     uint32_t *d_general = nullptr;  // [1 + general_cap] plaintexts the fast fused kernel declined (count, indices)
     size_t general_cap  = 0;
@@ -149,6 +150,8 @@ struct Context
     // qualifies (encrypt_sym dispatches on it).  A counter outside its window (~1e-7 per prime) is
     // redone on the device by the masked per-prime chain that follows the selection.
     bool small_batch_plan(size_t B, SpecPlan &plan) const;
+    // speculation or the plain per-prime chain for this batch (estimated chain latencies of both)
+    bool speculation_pays(size_t B, const SpecPlan &plan) const;
     int encrypt_sym_small(const SpecPlan &plan, const float *d_values, const uint8_t *d_share_seeds,
                           const uint8_t *d_seeds, uint32_t *d_c0, uint32_t *d_c1, uint32_t *d_ntt_pte,
                           int64_t *d_pte, uint8_t *d_status, hipStream_t st);

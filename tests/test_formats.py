@@ -107,3 +107,60 @@ def test_key_files_roundtrip(L, tmp_path):
     for j in range(npr):                                                             # fileops.c:172-204
         assert (np.fromfile(tmp_path / f"pk0_ntt_{n}_{q[j]}.dat", dtype=np.uint32) == pk0[j]).all()
         assert (np.fromfile(tmp_path / f"pk1_ntt_{n}_{q[j]}.dat", dtype=np.uint32) == pk1[j]).all()
+
+
+@pytest.mark.parametrize("shape,mode", [((1024, 1), "sym"), ((4096, 3), "sym"), ((4096, 3), "asym"),
+                                        ((16384, 6), "sym")], ids=["C1", "C2", "C3", "C4"])
+def test_adapter_reader_roundtrip(L, tmp_path, shape, mode):
+    """SEAL-side closure as far as this image allows: ciphertexts of the four encrypting
+    BASELINE shapes, written by the product's text writer in the adapter's test order (values line, then per
+    prime a c0 and a c1 line; device/test/api_tests.c:30-42,75-90), are read back by a restatement of the
+    adapter's own reader (tests/adapter_reader.py: poly_string_file_load / ct_string_file_load with the file
+    position threaded through three consecutive tests) and reconstruct exactly the uint64
+    [component][prime][coeff] record the SEAL-layout packer builds -- and the values the writer printed
+    parse back to the floats within the printer's precision."""
+    import vectors as V
+    from adapter_reader import read_tests
+    from oracle.pyoracle import Oracle
+    n, npr = shape
+    o = Oracle(n, npr)
+    sk = V.secret_key(n)
+    ntests = 3
+    vals = V.bench_values(ntests, n, first=5)
+    ss, sd = V.bench_seeds(ntests, first=5)
+    if mode == "asym":
+        pk0, pk1 = o.gen_pk(sk, bytes(64), bytes(range(64)))
+    path = str(tmp_path / "ct.txt").encode()
+    want = []
+    for t in range(ntests):
+        r = (o.encrypt_sym(vals[t], ss[t].tobytes(), sd[t].tobytes(), sk) if mode == "sym"
+             else o.encrypt_asym(vals[t], sd[t].tobytes(), pk0, pk1))
+        c0, c1 = np.ascontiguousarray(r["c0"]), np.ascontiguousarray(r["c1"])
+        assert L.se_amd_write_ciphertext_text(path, 1 if t else 0, vals[t].ctypes.data_as(C.c_void_p), n // 2,
+                                              c0.ctypes.data_as(C.c_void_p), c1.ctypes.data_as(C.c_void_p),
+                                              n, npr) == 0
+        packed = np.zeros(2 * npr * n, dtype=np.uint64)
+        L.se_amd_pack_seal_ciphertext_host(c0.ctypes.data_as(C.c_void_p), c1.ctypes.data_as(C.c_void_p), n, npr,
+                                           packed.ctypes.data_as(C.c_void_p))
+        want.append(packed)
+    got = read_tests(open(path.decode(), "rb").read(), n, npr, ntests)
+    q = np.array(o.q, dtype=np.uint64)
+    for t in range(ntests):
+        v, ct = got[t]
+        assert np.array_equal(ct, want[t]), t
+        assert v.shape == (n // 2,) and np.abs(v - vals[t].astype(np.float64)).max() < 1e-4
+        # what SEAL's context checks on load: every residue below its prime (is_data_valid_for)
+        assert (ct.reshape(2, npr, n) < q[None, :, None]).all()
+
+
+def test_adapter_reader_token_rules():
+    """The reader's corner rules the writer must respect: a '}' glued to the last value would DROP that value
+    (the token containing '}' ends the object unread), commas are stripped, the object name is ignored, and a
+    second call continues from the returned position."""
+    from adapter_reader import poly_string_file_load
+    data = b"x : { 1, 2, 3 }\nyy : { 4, 5 }\nz : { 6, 7}\n"
+    rows, pos = poly_string_file_load(data, 2, 0, "u64")
+    assert rows == [[1, 2, 3], [4, 5]]
+    rows, pos = poly_string_file_load(data, 1, pos, "u64")
+    assert rows == [[6]]                       # "7}" is the closing token: the glued value is lost
+    assert poly_string_file_load(data, 1, pos, "u64")[0] == []

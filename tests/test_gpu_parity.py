@@ -81,10 +81,11 @@ def test_sample_uniform_vs_oracle(env, shape):
             row.append(a)
         exp.append(row)
         ectr.append(ctr)
-    # flags 0: helper waves precompute redraw candidates during the squeeze (small-batch shape);
-    # flags 16: helper waves only pool the redraw phase; flags 8: wave-local redraw phase (the
-    # shape a full 65 536 batch runs)
-    for flags in (0, 8, 16):
+    # flags 0: a batch this small takes the WAVE-per-ciphertext kernel (k_sample_uniform_wave); 32 forces the
+    # lane-per-ciphertext kernel, in its three shapes: + 0 helper waves precompute redraw candidates during the
+    # squeeze (small-batch shape); + 16 helper waves only pool the redraw phase; + 8 wave-local redraw phase
+    # (the shape a full 65 536 batch runs)
+    for flags in (0, 32, 32 + 8, 32 + 16):
         ctx = env["pkg"].Context(n, npr)
         ctx.set_debug_flags(flags)
         out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
@@ -135,7 +136,8 @@ def test_sample_uniform_reject_list_overflow_path(env):
         for j in range(npr):
             exp[b, j], ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
     for cap in (0, 1, 7, 64):
-        for flags in (0, 8, 16):      # speculating helpers / no helpers / pooling-only helpers
+        # wave form (marker scan by the whole wave) / lane form: speculating helpers, no helpers, pooling-only
+        for flags in (0, 32, 32 + 8, 32 + 16):
             ctx = env["pkg"].Context(n, npr)
             ctx.set_reject_list_capacity(cap)
             ctx.set_debug_flags(flags)
@@ -207,6 +209,52 @@ def test_host_pipeline_large_pieces(env):
     assert (r["c0"] == host_u32(d0)).all() and (r["c1"] == host_u32(d1)).all()
 
 
+@pytest.mark.parametrize("shape", V.ALL_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_sample_uniform_wave_form_equals_lane_form(env, shape):
+    """The wave-per-ciphertext kernel (one Keccak state over the 64 lanes of a wave: DPP row shifts,
+    v_permlane16/32_swap, ds_bpermute) against the lane-per-ciphertext kernel and the oracle: ragged batch
+    sizes around a workgroup (4 waves), non-zero start counters, end counters, forced beyond its dispatch
+    threshold (flag 64) at a size where the lane form runs full workgroups, and a masked redo launch shape."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    o = Oracle(n, npr)
+    for B in (1, 3, 4, 5, 9):
+        seeds = seeds_np(B, f"wave-{n}-{B}")
+        cin = (np.arange(B, dtype=np.int64) * 1234567 + (1 << 33)) * (B % 2)
+        ctx = env["pkg"].Context(n, npr)
+        outs = []
+        for flags in (0, 32):
+            ctx.set_debug_flags(flags)
+            out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+            cout = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+            ctx.sample_uniform(dev_t(env, seeds), out, ctr_in=dev_t(env, cin), ctr_out=cout)
+            torch.cuda.synchronize()
+            outs.append((host_u32(out), cout.cpu().numpy()))
+        assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all(), B
+        for b in range(B):
+            ctr = int(cin[b])
+            for j in range(npr):
+                a, ctr = o.sample_uniform(j, seeds[b].tobytes(), ctr)
+                assert (outs[0][0][b, j] == a).all(), (B, b, j)
+            assert int(outs[0][1][b]) == ctr
+        ctx.close()
+    if n <= 4096:
+        B = 700                                   # forced wave form well beyond a few waves per CU
+        seeds = seeds_np(B, f"wave-big-{n}")
+        ctx = env["pkg"].Context(n, npr)
+        res = []
+        for flags in (64, 32):
+            ctx.set_debug_flags(flags)
+            out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+            cout = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+            ctx.sample_uniform(dev_t(env, seeds), out, ctr_out=cout)
+            torch.cuda.synchronize()
+            res.append((out.clone(), cout.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        ctx.close()
+
+
 def test_sample_uniform_speculation_shortfall_path(env):
     """Helper waves precompute spec_cap redraw candidates per ciphertext; when a ciphertext needs
     more, the rest goes through the pooled loop.  Forced here with tiny capacities."""
@@ -224,6 +272,7 @@ def test_sample_uniform_speculation_shortfall_path(env):
         ectr.append(ctr)
     for cap in (1, 8, 70, 90):
         ctx = env["pkg"].Context(n, npr)
+        ctx.set_debug_flags(32)                  # the lane-per-ciphertext kernel (the wave form has no helpers)
         ctx.set_speculation_capacity(cap)
         out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
         ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
@@ -430,7 +479,8 @@ def test_all_pipeline_shapes_agree(env, shape):
     for overlap in (0, 1):
         for split in (0, 1):
             ctx.set_pipeline(overlap, split)
-            ctx.set_debug_flags(8 if (overlap + split) % 2 else 0)   # helper waves on / off
+            # lane form with helper waves on / off, and (flags 0) the wave-per-ciphertext form
+            ctx.set_debug_flags({0: 32, 1: 32 + 8, 2: 0}[overlap + split])
             c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
             c1 = torch.zeros_like(c0)
             ntt_pte = torch.zeros_like(c0)
@@ -793,7 +843,7 @@ def test_small_batch_prime_speculation(env, n, npr, B):
     vals = V.bench_values(B, n, first=31)
     ss, sd = V.bench_seeds(B, first=900)
     exp = [o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk) for b in range(B)]
-    for flags in (0, 256):
+    for flags in (0, 256, 32, 32 + 256):           # wave-per-ciphertext chains / lane-per-ciphertext chains
         ctx.set_debug_flags(flags)
         for rep in range(2):                       # second call reuses streams and scratch
             r = ctx.encrypt_sym_host(vals, ss, sd, want_extra=True)
