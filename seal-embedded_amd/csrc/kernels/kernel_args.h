@@ -72,6 +72,7 @@ struct TernaryArgs
     uint32_t B;
     const uint64_t *ctr_in;  // optional [B]: start counters (NULL = 0, the encrypt path)
     uint32_t num_cus;        // compute units of the device (0 = 256)
+    uint32_t debug_flags;    // 32 = always the lane-per-ciphertext kernel (tests)
 };
 
 hipError_t launch_encode_encrypt(const DevParams &, const DevTables &, const EncArgs &, int mode,

@@ -741,6 +741,77 @@ __global__ __launch_bounds__(MAXT) void k_sample_ternary(TernaryArgs A)
     if (A.ctr_out && active) A.ctr_out[b] = ctr;
 }
 
+// The same sampler for a handful of ciphertexts: one WAVE per ciphertext (keccak.cuh, WaveKeccak).  The chain
+// of a ciphertext -- a 96-byte block per 96 coefficients, a 1-byte redraw for every byte >= 0xFE in byte
+// order, ~75 sequential permutations at n = 4096 -- costs ~3.3 us per permutation instead of ~10 us; the 12
+// lanes that hold the block's bytes turn their 8 bytes into codes and reject flags, the redraws are resolved
+// one at a time in position order exactly as sample.c:226-238 does.
+__global__ __launch_bounds__(256) void k_sample_ternary_wave(TernaryArgs A)
+{
+    const int lane  = threadIdx.x & 63;
+    const size_t b  = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= A.B) return;   // wave-uniform
+    const uint32_t n       = A.n;
+    const uint32_t nblocks = (n + 95) / 96;
+    const uint8_t *seedp   = A.seeds + b * kSeedBytes;
+    int8_t *out            = A.codes + b * n;
+    uint64_t ctr           = A.ctr_in ? A.ctr_in[b] : 0;
+    WaveKeccak wk;
+    wave_keccak_init(wk, lane);
+    for (uint32_t blk = 0; blk < nblocks; blk++)
+    {
+        wave_prng_absorb(wk, seedp, ctr, lane);
+        ctr++;
+        wave_keccak_f1600(wk);
+        const uint32_t base = blk * 96, stop = min(96u, n - base);   // stop is a multiple of 8 for n = 2^k >= 1024
+        const bool mine     = wk.index >= 0 && 8u * (uint32_t)wk.index < stop;
+        uint32_t pend       = 0;   // this lane's rejected bytes, bit k = byte 8 * index + k
+        if (mine)
+        {
+            uint32_t c[2];
+            const uint32_t w[2] = {wk.lo, wk.hi};
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+            {
+                uint32_t codes = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const uint32_t r = (w[h] >> (8 * k)) & 0xFFu;
+                    pend |= (r >= 0xFEu ? 1u : 0u) << (4 * h + k);
+                    codes |= mod3_u8(r) << (8 * k);
+                }
+                c[h] = codes;
+            }
+            *reinterpret_cast<uint2 *>(out + base + 8 * wk.index) = make_uint2(c[0], c[1]);
+        }
+        // redraws, in byte order (primary lanes ascend with the state-lane index)
+        uint64_t pm = __ballot(pend != 0);
+        while (pm != 0)
+        {
+            const int src       = __builtin_ctzll(pm);
+            const uint32_t bits = (uint32_t)__shfl((int)pend, src);
+            const uint32_t k    = (uint32_t)__builtin_ctz(bits);
+            const uint32_t idx  = (uint32_t)__shfl(wk.index, src);
+            for (;;)
+            {
+                wave_prng_absorb(wk, seedp, ctr, lane);
+                ctr++;
+                wave_keccak_f1600(wk);
+                const uint32_t r = (uint32_t)__shfl((int)wk.lo, 1) & 0xFFu;   // byte 0: state lane (0, 0) = wave lane 1
+                if (r < 0xFEu)
+                {
+                    if (lane == 0) out[base + 8 * idx + k] = (int8_t)mod3_u8(r);
+                    break;
+                }
+            }
+            if (lane == src) pend &= pend - 1;
+            pm = __ballot(pend != 0);
+        }
+    }
+    if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
+}
+
 // Raw PRNG blocks for tests: out[i] = SHAKE256(seed[i] || le64(ctr[i]))[0 : outlen], lane per block.
 __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs,
                                                     uint8_t *out, uint32_t outlen, uint32_t count)
@@ -871,6 +942,12 @@ hipError_t launch_sample_cbd(const CbdArgs &A, hipStream_t st)
 hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
 {
     if (A.B == 0) return hipSuccess;
+    if (A.B <= uniform_wave_limit(A.num_cus) && !(A.debug_flags & 32))
+    {
+        // a handful of chains: one wave per ciphertext (see k_sample_uniform_wave)
+        hipLaunchKernelGGL(k_sample_ternary_wave, dim3((A.B + 3) / 4), dim3(256), 0, st, A);
+        return hipGetLastError();
+    }
     unsigned threads, grid_x;
     size_t lds;
     chain_geometry(A.B, A.num_cus, threads, grid_x, lds);

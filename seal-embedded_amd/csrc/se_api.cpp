@@ -261,7 +261,7 @@ int se_amd_sample_ternary_device(se_amd_ctx *ctx, const uint8_t *d_seeds, size_t
     if (!ctx || !d_seeds || !d_codes) return SE_ERR_INVALD_ARGUMENT;
     SEAMD_HIP(hipSetDevice(ctx->c.device));
     seamd::TernaryArgs ta{d_seeds, d_codes, d_ctr_out, (uint32_t)ctx->c.hp.n, (uint32_t)B, nullptr,
-                          (uint32_t)ctx->c.num_cus};
+                          (uint32_t)ctx->c.num_cus, ctx->c.debug_flags};
     SEAMD_HIP(seamd::launch_sample_ternary(ta, as_stream(stream)));
     return SE_SUCCESS;
 }

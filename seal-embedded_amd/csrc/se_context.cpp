@@ -852,7 +852,7 @@ int Context::encrypt_asym_impl(const float *d_values, size_t B, const uint8_t *d
     size_t nchunks  = overlap ? asym_chunks : 1;
     if (nchunks > (size_t)kMaxPrimes) nchunks = kMaxPrimes;   // one join event per chunk
     if (nchunks < 1 || B < 4096 * nchunks) nchunks = 1;        // small batches: one chunk
-    TernaryArgs ta{d_seeds, d_ucodes, d_ctr, n, (uint32_t)B, nullptr, (uint32_t)num_cus};
+    TernaryArgs ta{d_seeds, d_ucodes, d_ctr, n, (uint32_t)B, nullptr, (uint32_t)num_cus, debug_flags};
     stage_begin(2, st);
     SEAMD_HIP(launch_sample_ternary(ta, st));
     stage_end(st);

@@ -293,7 +293,15 @@ def test_sample_ternary_and_cbd_vs_oracle(env, n):
     seeds = seeds_np(B, f"tern-{n}")
     codes = torch.zeros((B, n), dtype=torch.int8, device=env["dev"])
     ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
+    # a batch this small takes the wave-per-ciphertext kernel; flag 32 forces the lane-per-ciphertext one
+    ctx.set_debug_flags(32)
+    lane_codes = torch.zeros_like(codes)
+    lane_ctr = torch.zeros_like(ctr_out)
+    ctx.sample_ternary(dev_t(env, seeds), lane_codes, lane_ctr)
+    ctx.set_debug_flags(0)
     ctx.sample_ternary(dev_t(env, seeds), codes, ctr_out)
+    torch.cuda.synchronize()
+    assert torch.equal(codes, lane_codes) and torch.equal(ctr_out, lane_ctr)
     err = torch.zeros((B, 2 * n), dtype=torch.int8, device=env["dev"])
     ctx.sample_cbd(dev_t(env, seeds), err, 2 * (n // 16), ctr_base=ctr_out)
     torch.cuda.synchronize()
