@@ -26,6 +26,17 @@
 
 namespace seamd {
 
+// Synchronisation diet of the transforms (transform.cuh, RedealSync: wave-local first / last exchange, leading
+// barriers): built under -DSEAMD_FAST_SYNC.  Measured neutral on every workload (10 of 24 workgroup barriers
+// per plaintext gone, C5 31.47 / 31.75 ms against 31.47 / 31.53 ms, profiles/r03_ab_sync_shuffle.log) -- the
+// barriers are not what the transform kernels wait for -- so the default stays the simpler form (every
+// exchange: write, barrier, read, barrier).
+#ifdef SEAMD_FAST_SYNC
+constexpr bool kFastSync = true;
+#else
+constexpr bool kFastSync = false;
+#endif
+
 
 __device__ __forceinline__ void load16(uint32_t (&v)[16], const uint32_t *p)
 {
@@ -216,17 +227,20 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     __syncthreads();
 
     // inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183)
+    // kFastSync (transform.cuh, RedealSync): the first exchange is wave-local, the others lead with their
+    // barrier.  The barrier above separates the gather's reads from it; the workgroup reduction below is the
+    // barrier behind it.
     auto plain_ifft = [&]() {
 #ifdef SEAMD_NO_REAL_PASS0
-        ifft_tiles<LOGN>(re, im, T.ifft_w, plane, t);
+        ifft_tiles<LOGN, false, false, kFastSync>(re, im, T.ifft_w, plane, t);
 #else
-        ifft_tiles<LOGN, true>(re, im, T.ifft_w, plane, t);  // real input: short butterflies in pass 0
+        ifft_tiles<LOGN, true, false, kFastSync>(re, im, T.ifft_w, plane, t);  // real input: short butterflies in pass 0
 #endif
     };
     if constexpr (BRANCH_EXACT)
     {
         if (wg_nonfinite)
-            ifft_tiles<LOGN, false, true>(re, im, T.ifft_w, plane, t);
+            ifft_tiles<LOGN, false, true, kFastSync>(re, im, T.ifft_w, plane, t);
         else
             plain_ifft();
     }
@@ -476,7 +490,12 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
             reduce_signed16(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
                                                                           // symmetric kernel keeps the exact form
-            ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            // the last exchange of the NTT runs wave-locally in the wave's chunk of the transpose region
+            // (which to_quads reuses right after: same wave, program order)
+            if constexpr (QUADS && kFastSync)
+                ntt_tiles<LOGN, 64 * QSTRIDE>(x, RW, q, lds32, t, qlds);
+            else
+                ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             to_quads(x);
