@@ -655,6 +655,9 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef SEAMD_NTT_FUSE_PRIO
+    __builtin_amdgcn_s_setprio(SEAMD_NTT_FUSE_PRIO);
+#endif
     uint32_t *lds32  = reinterpret_cast<uint32_t *>(smem);
     const int t      = threadIdx.x;
     const size_t b   = blockIdx.x;
