@@ -50,6 +50,8 @@ struct UniformArgs
     const uint8_t *prime_of;  // optional [B]: ciphertext b samples ONLY prime prime_of[b], into output row b
                               // (out_primes = 1; prime_lo / prime_hi / out_prime_base are ignored): the virtual
                               // ciphertexts of ALL guessed primes of the prime speculation in ONE launch
+    uint32_t *nrej;           // staged form only: [B] rejected coefficients of the polynomial (k_bulk_pair ->
+                              // k_resolve_wave)
 };
 // Launches of at most this many ciphertexts take the wave-per-ciphertext kernel (k_sample_uniform_wave):
 // 16 waves per CU = 4 per SIMD, where its ~7.8 us per permutation still beats the lane form's 8.6-10.7 us
@@ -90,6 +92,10 @@ hipError_t launch_ntt_polys(const DevParams &, const DevTables &, int j, uint32_
 hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, size_t count,
                              hipStream_t);
 hipError_t launch_sample_uniform(const DevParams &, const UniformArgs &, hipStream_t);
+// staged form, one prime per launch (kernels/samplers.hip: k_bulk_pair, k_candidates, k_resolve_wave)
+hipError_t launch_uniform_bulk_pair(const DevParams &, const UniformArgs &, hipStream_t);
+hipError_t launch_uniform_candidates(const UniformArgs &, hipStream_t);
+hipError_t launch_uniform_resolve(const DevParams &, const UniformArgs &, hipStream_t);
 // Small-batch prime speculation (se_context.cpp, encrypt_sym_small): the uniform sampler of prime
 // j >= 1 is run for every plausible start counter of a window at once ("virtual ciphertexts"), so
 // the primes of one ciphertext no longer wait for each other.

@@ -444,6 +444,222 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
 }
 
 // ------------------------------------------------------------------------------------------
+// The redraw phase of one polynomial by one WAVE (used by k_sample_uniform_wave and k_resolve_wave): `need`
+// rejected coefficients take the accepted candidates of the stream block(ctr)[0:4], block(ctr + 1)[0:4], ...
+// in counter order; a candidate is drawn -- `ctr` advanced -- only while one is still needed (sample.c:50-56).
+// 64 candidates per round, one per lane: the first `row_len` come precomputed from `row` (k_candidates), the
+// rest are computed here in the lane-per-state form.  The r-th accepted candidate of a round goes to the
+// (done + r)-th rejected position: from the reject list while it holds all of them, otherwise the rejected
+// positions are the marker words of the polynomial, found by a wave-wide scan (rare: tiny list capacities).
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wave_redraws(uint32_t q, uint32_t crh, uint32_t bound, uint32_t *mypoly,
+                                             const uint32_t *mylist, uint32_t rej_cap, uint32_t need,
+                                             const uint32_t (&seed)[16], uint64_t &ctr, const uint32_t *row,
+                                             uint32_t row_len, int lane)
+{
+    const uint64_t lt  = (1ull << lane) - 1ull;   // lanes below this one
+    const bool by_list = need <= rej_cap;
+    uint32_t done = 0, scanpos = 0, t = 0;         // t: candidates of `row` already looked at
+    while (need > 0)
+    {
+        uint32_t x, cnt;                            // this lane's candidate; candidates in this round
+        if (t < row_len)
+        {
+            cnt = min(64u, row_len - t);
+            x   = (uint32_t)lane < cnt ? __hip_atomic_load(row + t + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0xFFFFFFFFu;
+            t += cnt;
+        }
+        else
+        {
+            cnt = 64;
+            KeccakState cs;
+            prng_absorb(cs, seed, ctr + (uint64_t)lane);
+            keccak_f1600_fresh(cs);                 // only cs.lo[0] is consumed
+            x = cs.lo[0];
+        }
+        const bool acc     = (uint32_t)lane < cnt && x < bound;
+        const uint64_t am  = __ballot(acc);
+        const uint32_t pre = (uint32_t)__popcll(am & lt);      // accepted candidates before this one
+        const bool take    = acc && pre < need;                 // drawn (pre < need) and accepted
+        const uint32_t val = barrett32(x, q, crh);
+        if (by_list)
+        {
+            if (take)
+            {
+                const uint32_t pos = __hip_atomic_load(mylist + done + pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mypoly[pos]        = val;
+            }
+        }
+        else
+        {
+            uint64_t tm = __ballot(take);
+            while (tm != 0)
+            {
+                const int src = __builtin_ctzll(tm);
+                tm &= tm - 1;
+                const uint32_t v = (uint32_t)__shfl((int)val, src);
+                for (;;)
+                {
+                    const uint32_t p  = scanpos + (uint32_t)lane;
+                    const uint32_t c  = p < (uint32_t)N
+                                            ? __hip_atomic_load(mypoly + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : 0u;
+                    const uint64_t mk = __ballot(p < (uint32_t)N && c == kRejMarker);
+                    if (mk != 0)
+                    {
+                        const uint32_t hit = scanpos + (uint32_t)__builtin_ctzll(mk);
+                        if (lane == 0) mypoly[hit] = v;
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __threadfence_block();
+                        scanpos = hit + 1;
+                        break;
+                    }
+                    scanpos += 64;
+                    if (scanpos >= (uint32_t)N) break;   // cannot happen: `need` markers are left
+                }
+            }
+        }
+        const uint32_t got = (uint32_t)__popcll(am);
+        if (got >= need)
+        {
+            // the need-th accepted candidate ends the draws: everything up to it was consumed
+            const uint64_t last = __ballot(acc && pre == need - 1);
+            ctr += (uint64_t)__builtin_ctzll(last) + 1;
+            done += need;
+            need = 0;
+        }
+        else
+        {
+            ctr += cnt;
+            done += got;
+            need -= got;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Staged form of the sampler for batches that leave SIMDs without a chain wave (one prime per launch):
+//   k_bulk_pair   the bulk squeeze, ONE ciphertext per LANE PAIR (keccak.cuh, KeccakHalf: 126 instructions per
+//                 round and lane instead of 190 -- the chain of a ciphertext, the critical path of the whole
+//                 step at n = 16384, gets ~1.5x shorter); writes residues / markers, the reject list and count
+//   k_candidates  block(ctr + 1 + k)[0:4], k < spec_cap, for every ciphertext: a plain throughput kernel on a
+//                 second stream BESIDE the chains (what the helper waves of k_sample_uniform do inside the
+//                 chain workgroups, at 160 VGPRs and pinned to the chains' SIMDs)
+//   k_resolve_wave  one wave per ciphertext: consumes the candidates in counter order (wave_redraws), patches
+//                 the rejected coefficients, leaves the next prime's start counter
+// Same values, same counters as k_sample_uniform (tests: every shape against the oracle and the other forms).
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
+{
+    constexpr int N          = 1 << LOGN;
+    constexpr int FULL_STEPS = (N * 4) / 136;
+    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;
+    static_assert(TAIL_WORDS % 2 == 0 && TAIL_WORDS <= 32, "the tail is a whole number of state lanes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];   // reserved: one workgroup per CU
+    (void)pin_lds;
+    const uint32_t part = threadIdx.x & 1u;   // 0: low halves (and owner of the ciphertext's bookkeeping)
+    const size_t bq     = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const bool active   = bq < A.B;
+    const size_t b      = active ? bq : (size_t)A.B - 1;   // idle pairs shadow the last ciphertext, store nothing
+    const uint32_t j    = A.prime_lo;
+    const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
+    uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+    uint32_t *mylist = A.rej_list + b * A.rej_cap;
+    uint32_t seed[16];
+    load_seed(seed, A.seeds, b);
+    KeccakHalf st;
+    prng_absorb_half(st, seed, A.ctr_in ? A.ctr_in[b] : 0, part);
+    uint32_t nrej = 0;   // maintained on the owner lane
+
+    // one squeeze step: word 2 i + part of the step comes from st.w[i]
+    auto emit = [&](uint32_t idx, int lanes64) {
+        uint32_t mask = 0;   // bit (31 - i): word i of this lane rejected
+#pragma unroll
+        for (int i = 0; i < 17; i++)
+        {
+            if (i < lanes64)
+            {
+                const uint32_t x = st.w[i];
+                const bool rej   = x >= bound;
+                const uint32_t r = barrett32(x, q, crh);
+                mask |= (rej ? 0x80000000u : 0u) >> i;
+                if (active) mypoly[idx + 2 * i + part] = rej ? kRejMarker : r;
+            }
+        }
+        const uint32_t other = pair_swap(mask);
+        if (__any((mask | other) != 0))
+        {
+            // owner: both lanes' rejects in position order (word 2 i of the owner before word 2 i + 1 of the partner)
+            uint32_t m0 = part ? 0u : mask, m1 = part ? 0u : other;
+            while (m0 | m1)
+            {
+                const uint32_t i0 = m0 ? (uint32_t)__clz((int)m0) : 64u, i1 = m1 ? (uint32_t)__clz((int)m1) : 64u;
+                uint32_t pos;
+                if (i0 <= i1)
+                    pos = 2 * i0, m0 &= ~(0x80000000u >> i0);
+                else
+                    pos = 2 * i1 + 1, m1 &= ~(0x80000000u >> i1);
+                if (active && nrej < A.rej_cap) mylist[nrej] = idx + pos;
+                nrej++;
+            }
+        }
+    };
+    uint32_t idx = 0;
+    for (int step = 0; step < FULL_STEPS; step++)
+    {
+        keccak_half_f1600(st, part);
+        emit(idx, 17);
+        idx += 34;
+    }
+    if constexpr (TAIL_WORDS > 0)
+    {
+        keccak_half_f1600(st, part);
+        emit(idx, TAIL_WORDS / 2);
+    }
+    if (active && part == 0) A.nrej[b] = nrej;
+}
+
+// candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4]; consecutive threads = consecutive k of one ciphertext
+__global__ __launch_bounds__(256) void k_candidates(UniformArgs A)
+{
+    const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)A.B * A.spec_cap;
+    if (gid >= total) return;
+    const size_t b   = gid / A.spec_cap;
+    const uint32_t k = (uint32_t)(gid - b * A.spec_cap);
+    uint32_t seed[16];
+    load_seed(seed, A.seeds, b);
+    KeccakState st;
+    prng_absorb(st, seed, (A.ctr_in ? A.ctr_in[b] : 0) + 1 + k);
+    keccak_f1600_fresh<true>(st);   // only the first word is consumed
+    A.spec[gid] = st.lo[0];
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_resolve_wave(DevParams P, UniformArgs A)
+{
+    constexpr int N = 1 << LOGN;
+    const int lane  = threadIdx.x & 63;
+    const size_t b  = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= A.B) return;   // wave-uniform
+    const uint32_t j = A.prime_lo;
+    uint64_t ctr     = (A.ctr_in ? A.ctr_in[b] : 0) + 1;   // the bulk block took one counter
+    const uint32_t need = (A.debug_flags & 2) ? 0u : A.nrej[b];
+    if (need > 0)
+    {
+        uint32_t seed[16];
+        load_seed(seed, A.seeds, b);
+        uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+        wave_redraws<N>(P.q[j], P.cr_hi[j], P.bound[j], mypoly, A.rej_list + b * A.rej_cap, A.rej_cap, need, seed, ctr,
+                        A.spec ? A.spec + b * (size_t)A.spec_cap : nullptr, A.spec ? A.spec_cap : 0u, lane);
+    }
+    if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
+}
+
+// ------------------------------------------------------------------------------------------
 // The same sampler for a HANDFUL of ciphertexts: one WAVE per ciphertext (keccak.cuh, WaveKeccak).
 //
 // The bulk block of a polynomial is one sequential sponge squeeze (121 permutations at n = 4096, 482 at
@@ -531,77 +747,8 @@ __global__ __launch_bounds__(256) void k_sample_uniform_wave(DevParams P, Unifor
         __threadfence_block();
 
         // ---- redraws: 64 candidates block(ctr + lane)[0:4] per round -------------------------------
-        uint32_t need    = (A.debug_flags & 2) ? 0u : nrej;
-        uint32_t done    = 0;                       // rejected coefficients resolved so far
-        uint32_t scanpos = 0;                       // list-overflow form: next index to scan for a marker
-        const bool by_list = nrej <= A.rej_cap;     // else: the rejected positions are the marker words
-        while (need > 0)
-        {
-            KeccakState cs;
-            prng_absorb(cs, seed, ctr + (uint64_t)lane);
-            keccak_f1600_fresh(cs);                 // only cs.lo[0] is consumed
-            const uint32_t x   = cs.lo[0];
-            const bool acc     = x < bound;
-            const uint64_t am  = __ballot(acc);
-            const uint32_t pre = (uint32_t)__popcll(am & lt);      // accepted candidates before this one
-            const bool take    = acc && pre < need;                 // drawn (pre < need) and accepted
-            const uint32_t val = barrett32(x, q, crh);
-            if (by_list)
-            {
-                if (take)
-                {
-                    const uint32_t pos =
-                        __hip_atomic_load(mylist + done + pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    mypoly[pos] = val;
-                }
-            }
-            else
-            {
-                // rare (more rejections than list entries): the accepted candidates one by one, each to the
-                // next marker word found by a wave-wide scan
-                uint64_t tm = __ballot(take);
-                while (tm != 0)
-                {
-                    const int src = __builtin_ctzll(tm);
-                    tm &= tm - 1;
-                    const uint32_t v = (uint32_t)__shfl((int)val, src);
-                    for (;;)
-                    {
-                        const uint32_t p  = scanpos + (uint32_t)lane;
-                        const uint32_t c  = p < (uint32_t)N
-                                                ? __hip_atomic_load(mypoly + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                : 0u;
-                        const uint64_t mk = __ballot(p < (uint32_t)N && c == kRejMarker);
-                        if (mk != 0)
-                        {
-                            const uint32_t hit = scanpos + (uint32_t)__builtin_ctzll(mk);
-                            if (lane == 0) mypoly[hit] = v;
-                            __builtin_amdgcn_s_waitcnt(0);
-                            __threadfence_block();
-                            scanpos = hit + 1;
-                            break;
-                        }
-                        scanpos += 64;
-                        if (scanpos >= (uint32_t)N) break;   // cannot happen: `need` markers are left
-                    }
-                }
-            }
-            const uint32_t got = (uint32_t)__popcll(am);
-            if (got >= need)
-            {
-                // the need-th accepted candidate ends the draws: everything up to it was consumed
-                const uint64_t last = __ballot(acc && pre == need - 1);
-                ctr += (uint64_t)__builtin_ctzll(last) + 1;
-                done += need;
-                need = 0;
-            }
-            else
-            {
-                ctr += 64;
-                done += got;
-                need -= got;
-            }
-        }
+        wave_redraws<N>(q, crh, bound, mypoly, mylist, A.rej_cap, (A.debug_flags & 2) ? 0u : nrej, seed, ctr, nullptr,
+                        0u, lane);
         __builtin_amdgcn_s_waitcnt(0);
     }
     if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
@@ -928,6 +1075,60 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
 #undef SEAMD_LAUNCH_UNIFORM
 #undef SEAMD_LAUNCH_UNIFORM_P
 #undef SEAMD_LAUNCH_UNIFORM_T
+    return hipGetLastError();
+}
+
+// ---- staged form (one prime per launch; se_context.cpp runs k_candidates on a stream of its own) ----
+hipError_t launch_uniform_bulk_pair(const DevParams &P, const UniformArgs &A, hipStream_t st)
+{
+    if (A.B == 0) return hipSuccess;
+    if (!A.nrej || A.prime_hi != A.prime_lo + 1) return hipErrorInvalidValue;
+    // like chain_geometry: workgroups of w waves, one per CU (84 KiB of reserved LDS), w <= 8 pair waves
+    const size_t cus   = P.num_cus ? P.num_cus : 256;
+    const size_t waves = (2 * (size_t)A.B + 63) / 64;
+    size_t w           = (waves + cus - 1) / cus;
+    if (w < 1) w = 1;
+    if (w > 8) w = 8;
+    const unsigned threads = (unsigned)(w * 64), grid = (unsigned)((2 * (size_t)A.B + threads - 1) / threads);
+    const size_t lds = 84 * 1024;
+#define SEAMD_LAUNCH_PAIR(L)                                                                                    \
+    (void)hipFuncSetAttribute((const void *)k_bulk_pair<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_bulk_pair<L>), dim3(grid), dim3(threads), lds, st, P, A)
+    switch (P.logn)
+    {
+        case 10: SEAMD_LAUNCH_PAIR(10); break;
+        case 11: SEAMD_LAUNCH_PAIR(11); break;
+        case 12: SEAMD_LAUNCH_PAIR(12); break;
+        case 13: SEAMD_LAUNCH_PAIR(13); break;
+        case 14: SEAMD_LAUNCH_PAIR(14); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef SEAMD_LAUNCH_PAIR
+    return hipGetLastError();
+}
+
+hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st)
+{
+    const size_t total = (size_t)A.B * A.spec_cap;
+    if (total == 0 || !A.spec) return hipSuccess;
+    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_uniform_resolve(const DevParams &P, const UniformArgs &A, hipStream_t st)
+{
+    if (A.B == 0) return hipSuccess;
+    if (!A.nrej) return hipErrorInvalidValue;
+    const dim3 grid((A.B + 3) / 4), block(256);
+    switch (P.logn)
+    {
+        case 10: hipLaunchKernelGGL((k_resolve_wave<10>), grid, block, 0, st, P, A); break;
+        case 11: hipLaunchKernelGGL((k_resolve_wave<11>), grid, block, 0, st, P, A); break;
+        case 12: hipLaunchKernelGGL((k_resolve_wave<12>), grid, block, 0, st, P, A); break;
+        case 13: hipLaunchKernelGGL((k_resolve_wave<13>), grid, block, 0, st, P, A); break;
+        case 14: hipLaunchKernelGGL((k_resolve_wave<14>), grid, block, 0, st, P, A); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

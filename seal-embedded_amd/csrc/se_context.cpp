@@ -73,9 +73,12 @@ Context::~Context()
     for (auto &e : ev_prime)
         if (e) (void)hipEventDestroy(e);
     if (spec_stream) (void)hipStreamDestroy(spec_stream);
+    if (cand_stream) (void)hipStreamDestroy(cand_stream);
+    for (auto &e : ev_cand)
+        if (e) (void)hipEventDestroy(e);
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
                     d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general, d_compact,
-                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail, d_sp_prime};
+                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail, d_sp_prime, d_nrej};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -220,15 +223,16 @@ int Context::ensure_scratch(size_t B, size_t rows)
     const size_t n = hp.n;
     if (B > scratch_cap)
     {
-        void *old[] = {d_err, d_ucodes, d_ctr, d_compact};
+        void *old[] = {d_err, d_ucodes, d_ctr, d_compact, d_nrej};
         for (void *p : old)
             if (p) (void)hipFree(p);
-        d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_compact = nullptr;
+        d_err = nullptr, d_ucodes = nullptr, d_ctr = nullptr, d_compact = nullptr, d_nrej = nullptr;
         scratch_cap = 0;
         SEAMD_HIP(hipMalloc((void **)&d_err, B * 2 * n));
         SEAMD_HIP(hipMalloc((void **)&d_ucodes, B * n));
         SEAMD_HIP(hipMalloc((void **)&d_ctr, B * sizeof(uint64_t)));
         SEAMD_HIP(hipMalloc((void **)&d_compact, B));
+        SEAMD_HIP(hipMalloc((void **)&d_nrej, B * sizeof(uint32_t)));
         scratch_cap = B;
     }
     if (rows > rows_cap)
@@ -643,15 +647,44 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, ax));
         stage_end(ax);
     }
+    // Staged sampler (kernels/samplers.hip: k_bulk_pair / k_candidates / k_resolve_wave) for batches between
+    // the wave form's limit and one PAIR wave per SIMD (B <= 128 per CU): the chain launches are the critical
+    // path of this pipeline, and a ciphertext per lane pair shortens each by ~1.5x; the candidates, which the
+    // helper waves of k_sample_uniform compute inside the chain workgroups, become a throughput kernel on a
+    // stream of its own.  debug_flags 512 forces it, 1024 forbids it.
+    const bool staged = overlap && !(debug_flags & (32 | 1024)) &&
+                        ((B > uniform_wave_limit((unsigned)num_cus) && B <= (size_t)128 * (size_t)num_cus) ||
+                         (debug_flags & 512));
+    if (staged && !cand_stream)
+    {
+        SEAMD_HIP(hipStreamCreateWithFlags(&cand_stream, hipStreamNonBlocking));
+        for (auto &e : ev_cand) SEAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     for (uint32_t j = 0; j < np; j++)
     {
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
                        j,             j + 1,               np,    d_spec,      spec_cap,
-                       0,             debug_flags,         nullptr, 0, fill};
-        stage_begin(1, st);
-        SEAMD_HIP(launch_sample_uniform(dp, ua, st));
-        stage_end(st);
+                       0,             debug_flags,         nullptr, 0, fill, nullptr, d_nrej};
+        if (staged)
+        {
+            //   C : (start counters of prime j known) k_candidates_j ───────────┐
+            //   S : k_bulk_pair_j ─────────────────────────────────── (wait C) k_resolve_wave_j
+            SEAMD_HIP(hipStreamWaitEvent(cand_stream, j ? ev_prime[j - 1] : ev_fork, 0));
+            SEAMD_HIP(launch_uniform_candidates(ua, cand_stream));
+            SEAMD_HIP(hipEventRecord(ev_cand[j], cand_stream));
+            stage_begin(1, st);
+            SEAMD_HIP(launch_uniform_bulk_pair(dp, ua, st));
+            SEAMD_HIP(hipStreamWaitEvent(st, ev_cand[j], 0));
+            SEAMD_HIP(launch_uniform_resolve(dp, ua, st));
+            stage_end(st);
+        }
+        else
+        {
+            stage_begin(1, st);
+            SEAMD_HIP(launch_sample_uniform(dp, ua, st));
+            stage_end(st);
+        }
         if (late_encode && j == 0)
         {
             SEAMD_HIP(hipStreamWaitEvent(st, ev_cbd, 0));

@@ -70,6 +70,10 @@ struct Context
     // ... and the bytes their output rows may take (one n-word row per virtual ciphertext)
     size_t small_bytes = getenv("SE_AMD_SMALL_BYTES") ? (size_t)atoll(getenv("SE_AMD_SMALL_BYTES")) : ((size_t)1 << 30);
     hipStream_t spec_stream = nullptr;   // the guesses of ALL primes run as one launch on it
+    // staged sampler (k_bulk_pair / k_candidates / k_resolve_wave): candidates on a stream of their own
+    hipStream_t cand_stream = nullptr;
+    hipEvent_t ev_cand[kMaxPrimes] = {};
+    uint32_t *d_nrej = nullptr;          // [scratch_cap] rejected coefficients of the current polynomial
     uint8_t *d_compact  = nullptr;  // [scratch_cap] k_encode_rns -> k_ntt_fuse: plaintext b travels as one int32 row
     uint32_t *d_general = nullptr;  // [1 + general_cap] plaintexts the fast fused kernel declined (count, indices)
     size_t general_cap  = 0;

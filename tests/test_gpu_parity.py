@@ -255,6 +255,46 @@ def test_sample_uniform_wave_form_equals_lane_form(env, shape):
         ctx.close()
 
 
+@pytest.mark.parametrize("shape,B", [((1024, 1), 70), ((4096, 3), 131), ((8192, 6), 33), ((16384, 6), 70)],
+                         ids=lambda v: str(v))
+def test_staged_sampler_pipeline(env, shape, B):
+    """The staged form of the symmetric pipeline (one ciphertext per LANE PAIR for the bulk squeeze --
+    KeccakHalf --, the redraw candidates as a throughput kernel on a stream of its own, one wave per ciphertext
+    to resolve them; chosen for batches between the wave form's limit and one pair wave per SIMD, forced here
+    with debug flag 512) against the oracle: odd batch sizes (idle pairs, partial workgroups), a candidate row
+    that is too short (the rest is computed by the resolving wave), a reject list that is too short (marker
+    scan), and repeated calls on the same scratch."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    o = Oracle(n, npr)
+    sk = V.secret_key(n, seed=17)
+    vals = V.bench_values(B, n, first=900)
+    ss, sd = V.bench_seeds(B, first=900)
+    exp = [o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk) for b in range(B)]
+    for spec_cap, rej_cap in ((None, None), (8, None), (None, 5), (1, 0)):
+        ctx = env["pkg"].Context(n, npr)
+        ctx.set_secret_key(sk)
+        ctx.set_pipeline(1, 1)
+        ctx.set_debug_flags(512)
+        if spec_cap is not None:
+            ctx.set_speculation_capacity(spec_cap)
+        if rej_cap is not None:
+            ctx.set_reject_list_capacity(rej_cap)
+        for rep in range(2):
+            c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+            c1 = torch.zeros_like(c0)
+            st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+            ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, status=st)
+            torch.cuda.synchronize()
+            g0, g1 = host_u32(c0), host_u32(c1)
+            assert bool(st.all())
+            for b in range(B):
+                assert (g1[b] == exp[b]["c1"]).all(), (spec_cap, rej_cap, rep, b)
+                assert (g0[b] == exp[b]["c0"]).all(), (spec_cap, rej_cap, rep, b)
+        ctx.close()
+
+
 def test_sample_uniform_speculation_shortfall_path(env):
     """Helper waves precompute spec_cap redraw candidates per ciphertext; when a ciphertext needs
     more, the rest goes through the pooled loop.  Forced here with tiny capacities."""
