@@ -656,7 +656,7 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     constexpr int CTOP = LOGN - 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef SEAMD_NTT_FUSE_PRIO
-    __builtin_amdgcn_s_setprio(SEAMD_NTT_FUSE_PRIO);
+    SEAMD_SETPRIO(SEAMD_NTT_FUSE_PRIO);
 #endif
     uint32_t *lds32  = reinterpret_cast<uint32_t *>(smem);
     const int t      = threadIdx.x;

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace seamd {
 
 struct KeccakState
@@ -206,12 +208,22 @@ __device__ __forceinline__ void prng_absorb(KeccakState &s, const uint32_t (&see
 // the SAME instruction sequence serves both lanes:
 //     R < 32 : lo' = lo << R | hi >> (32-R),  hi' = hi << R | lo >> (32-R)   = alignbit(own, partner, 32 - R)
 //     R > 32 : lo' = hi << (R-32) | lo >> (64-R),  hi' likewise              = alignbit(partner, own, 64 - R)
-// Per round and lane: 10 (parities) + 5 + 5 + 5 (D) + 25 (apply) + 24 + 24 (rho) + 25 (chi) + 3 (iota) = 126
+// Per round and lane: 10 (parities) + 5 + 5 (rol1 C) + 25 (folded theta) + 24 + 24 (rho) + 25 (chi) + 3 (iota) = 121
 // VALU instructions against 190 for the lane-per-state form: the chain of one ciphertext gets 1.5x shorter,
 // the chip does 1.33x the work -- a win exactly where the lane-per-state form leaves SIMDs idle (small
 // batches, single calls), a loss on a full chip.  Bit-identical by construction: the
 // same Boolean function of keccakf1600.c:51-316, other registers.
 // ------------------------------------------------------------------------------------------
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for_keccak(F &&f)
+{
+    if constexpr (BEGIN < END)
+    {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for_keccak<BEGIN + 1, END>(f);
+    }
+}
+
 struct KeccakHalf
 {
     uint32_t w[25];   // even lane: low halves, odd lane: high halves
@@ -234,45 +246,37 @@ __device__ __forceinline__ uint32_t rol64_half(uint32_t own, uint32_t partner)
         return __builtin_amdgcn_alignbit(partner, own, 64 - R);
 }
 
-#define SEAMD_RHOPI_HALF(SRC, DST, R)                                     {                                                                         const uint32_t t_ = s.w[SRC] ^ d[(SRC) % 5];                          if constexpr ((R) == 0)                                                   b[DST] = t_;                                                      else                                                                      b[DST] = rol64_half<((R) == 0 ? 1 : (R))>(t_, pair_swap(t_));     }
-
-// rc = this lane's half of the round constant
+// rc = this lane's half of the round constant.  theta is folded (A ^ D = xor3(A, C[x-1], rol1(C[x+1])): no D),
+// and rho runs in three sweeps -- all the theta outputs, all the partner fetches, all the funnel shifts -- so
+// that every v_mov_b32_dpp has independent instructions between it and the write of its source (a DPP read
+// needs two wait states after a VALU write: 8 s_nop per round in the straightforward order).
 __device__ __forceinline__ void keccak_half_round(KeccakHalf &s, uint32_t rc)
 {
-    uint32_t c[5], d[5], b[25];
+    constexpr int kSrcOfDst[25] = {0, 6, 12, 18, 24, 3, 9, 10, 16, 22, 1, 7, 13, 19, 20, 4, 5, 11, 17, 23, 2, 8, 14, 15, 21};
+    constexpr int kRho[25]      = {0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3,  10, 43,
+                                   25, 39, 41, 45, 15, 21, 8,  18, 2,  61, 56, 14};
+    uint32_t c[5], rl[5], t[25], p[25], b[25];
 #pragma unroll
     for (int x = 0; x < 5; x++) c[x] = xor3(xor3(s.w[x], s.w[x + 5], s.w[x + 10]), s.w[x + 15], s.w[x + 20]);
+    uint32_t cp[5];
 #pragma unroll
-    for (int x = 0; x < 5; x++)
-    {
-        const uint32_t cn = c[(x + 1) % 5];
-        d[x]              = c[(x + 4) % 5] ^ rol64_half<1>(cn, pair_swap(cn));
-    }
-    SEAMD_RHOPI_HALF(0, 0, 0);
-    SEAMD_RHOPI_HALF(1, 10, 1);
-    SEAMD_RHOPI_HALF(2, 20, 62);
-    SEAMD_RHOPI_HALF(3, 5, 28);
-    SEAMD_RHOPI_HALF(4, 15, 27);
-    SEAMD_RHOPI_HALF(5, 16, 36);
-    SEAMD_RHOPI_HALF(6, 1, 44);
-    SEAMD_RHOPI_HALF(7, 11, 6);
-    SEAMD_RHOPI_HALF(8, 21, 55);
-    SEAMD_RHOPI_HALF(9, 6, 20);
-    SEAMD_RHOPI_HALF(10, 7, 3);
-    SEAMD_RHOPI_HALF(11, 17, 10);
-    SEAMD_RHOPI_HALF(12, 2, 43);
-    SEAMD_RHOPI_HALF(13, 12, 25);
-    SEAMD_RHOPI_HALF(14, 22, 39);
-    SEAMD_RHOPI_HALF(15, 23, 41);
-    SEAMD_RHOPI_HALF(16, 8, 45);
-    SEAMD_RHOPI_HALF(17, 18, 15);
-    SEAMD_RHOPI_HALF(18, 3, 21);
-    SEAMD_RHOPI_HALF(19, 13, 8);
-    SEAMD_RHOPI_HALF(20, 14, 18);
-    SEAMD_RHOPI_HALF(21, 24, 2);
-    SEAMD_RHOPI_HALF(22, 9, 61);
-    SEAMD_RHOPI_HALF(23, 19, 56);
-    SEAMD_RHOPI_HALF(24, 4, 14);
+    for (int x = 0; x < 5; x++) cp[x] = pair_swap(c[x]);
+#pragma unroll
+    for (int x = 0; x < 5; x++) rl[x] = rol64_half<1>(c[x], cp[x]);   // this lane's half of rol1(C[x])
+#pragma unroll
+    for (int i = 0; i < 25; i++) t[i] = xor3(s.w[i], c[(i % 5 + 4) % 5], rl[(i % 5 + 1) % 5]);
+#pragma unroll
+    for (int i = 1; i < 25; i++) p[i] = pair_swap(t[i]);
+    // B[dst] = rol(t[src], rho[src]);  dst = y + 5 ((2x + 3y) mod 5) for src = x + 5y
+    static_for_keccak<0, 25>([&](auto dc) {
+        constexpr int dst = decltype(dc)::value;
+        constexpr int src = kSrcOfDst[dst];
+        constexpr int R   = kRho[src];
+        if constexpr (R == 0)
+            b[dst] = t[src];
+        else
+            b[dst] = rol64_half<(R == 0 ? 1 : R)>(t[src], p[src]);
+    });
 #pragma unroll
     for (int y = 0; y < 25; y += 5)
     {
@@ -281,7 +285,6 @@ __device__ __forceinline__ void keccak_half_round(KeccakHalf &s, uint32_t rc)
     }
     s.w[0] ^= rc;
 }
-#undef SEAMD_RHOPI_HALF
 
 // `part` = 0 on the even lane (low halves), 1 on the odd lane (high halves)
 __device__ __forceinline__ void keccak_half_f1600(KeccakHalf &s, uint32_t part)

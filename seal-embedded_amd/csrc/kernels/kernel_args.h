@@ -8,6 +8,16 @@
 
 namespace seamd {
 
+// Wave priorities of the per-prime pipeline (s_setprio; -DSEAMD_PRIO_OFF builds without them for A/B runs).
+// The chain launches are the critical path of a symmetric step: their waves win the VALU arbitration (3), the
+// per-prime transform kernel, which must keep pace with them, comes next (2), the throughput samplers (CBD,
+// redraw candidates) take what is left (0, the default).
+#ifdef SEAMD_PRIO_OFF
+#define SEAMD_SETPRIO(p) ((void)0)
+#else
+#define SEAMD_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 struct EncArgs
 {
     const float *values;

@@ -668,6 +668,16 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
                        0,             debug_flags,         nullptr, 0, fill, nullptr, d_nrej};
         if (staged)
         {
+            // Candidates per ciphertext: here they are pure throughput work beside the chains, and a
+            // ciphertext that needs more gets them from the resolving wave itself -- so mean + 1.5 sigma of the
+            // draws instead of the helper waves' mean + 4 sigma (every unused candidate is a wasted permutation:
+            // 384 -> 336 at n = 16384 is 4 % of the phase's instructions).
+            {
+                const double p_rej = (double)(0u - dp.bound[j]) / 4294967296.0;
+                const double mean  = (double)hp.n * p_rej / (1.0 - p_rej);
+                const uint32_t cap = ((uint32_t)(mean + 1.5 * sqrt((double)hp.n * p_rej) + 15.0)) & ~15u;
+                if (cap < ua.spec_cap) ua.spec_cap = cap ? cap : 16u;
+            }
             //   C : (start counters of prime j known) k_candidates_j ───────────┐
             //   S : k_bulk_pair_j ─────────────────────────────────── (wait C) k_resolve_wave_j
             SEAMD_HIP(hipStreamWaitEvent(cand_stream, j ? ev_prime[j - 1] : ev_fork, 0));
