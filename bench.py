@@ -64,8 +64,16 @@ DESCR = {
 }
 KERNEL_NAMES = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform", "ternary": "k_sample_ternary",
                 "encode_encrypt": "k_encode_encrypt", "encode_rns": "k_encode_rns", "ntt_fuse": "k_ntt_fuse"}
-# kernels a stage timer may cover when a stage is more than one kernel (none today)
-STAGE_KERNELS = {}
+# kernels a stage timer covers when a stage is more than one kernel: the general forms that pick up what the fast
+# kernels declined (normally empty launches), and the staged form of the uniform sampler (lane pairs for the bulk
+# squeeze, a candidate kernel on a stream of its own, one wave per ciphertext to resolve; mid-size batches)
+STAGE_KERNELS = {
+    "uniform": ("k_sample_uniform", "k_sample_uniform_wave", "k_bulk_pair", "k_candidates", "k_resolve_light",
+                "k_resolve_wave"),
+    "ternary": ("k_sample_ternary", "k_sample_ternary_wave"),
+    "encode_encrypt": ("k_encode_encrypt", "k_encode_encrypt_general"),
+    "encode_rns": ("k_encode_rns", "k_encode_rns_general"),
+}
 
 
 class Deadline:
@@ -588,6 +596,7 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         kms = ms / prof_steps
         alg = kbytes.get(s, 0) * B
         kernels.append({"kernel": KERNEL_NAMES[s], "ms_per_step": kms, "launches_per_step": cnt / prof_steps,
+                        "profiled_as": [k for k in STAGE_KERNELS.get(s, (KERNEL_NAMES[s],)) if k in pmc or k in sq],
                         "algorithmic_bytes": alg, "achieved": alg / (kms * 1e-3) / 1e9,
                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": stage_profile(pmc, s, "hbm_bytes_per_step")})
