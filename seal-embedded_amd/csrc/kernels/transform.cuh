@@ -107,6 +107,9 @@ enum RedealSync { kSyncBoth, kSyncLead, kLocal };
 template <int C_FROM, int C_TO, RedealSync SYNC = kSyncBoth, int WSTRIDE = 0, typename T>
 __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
 {
+#ifdef SEAMD_ABL_NOLDS   // timing ablation (WRONG results): exchanges cost nothing
+    return;
+#endif
     if constexpr (SYNC == kLocal)
     {
         static_assert((C_FROM == 0 && C_TO <= 4) || (C_TO == 0 && C_FROM <= 4), "wave-local exchanges only");
@@ -327,7 +330,11 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
             constexpr int g = decltype(gc)::value;
             // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
             const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
+#ifdef SEAMD_ABL_NOTAB   // timing ablation (WRONG results): no root-table loads
+            const double2 w = make_double2(0.7 + idx * 1e-9, 0.7);
+#else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
+#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
@@ -362,7 +369,11 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             const int idx   = N + ((8 >> b) - 1 + g) * (N / 16) + t;   // thread-major copy (se_types.h)
+#ifdef SEAMD_ABL_NOTAB
+            const double2 w = make_double2(0.7 + idx * 1e-9, 0.7);
+#else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
+#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int r  = decltype(rc)::value;
                 constexpr int e0 = (g << (b + 1)) | r;
@@ -447,7 +458,11 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
             constexpr int g = decltype(gc)::value;
             // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
             const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
+#ifdef SEAMD_ABL_NOTAB
+            const uint2 rw  = make_uint2(12345u + idx, 54321u);
+#else
             const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
+#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
