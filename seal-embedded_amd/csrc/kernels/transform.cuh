@@ -330,8 +330,10 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
             constexpr int g = decltype(gc)::value;
             // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
             const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
-#ifdef SEAMD_ABL_NOTAB   // timing ablation (WRONG results): no root-table loads
-            const double2 w = make_double2(0.7 + idx * 1e-9, 0.7);
+#ifdef SEAMD_ABL_NOTAB   // timing ablation (WRONG results): no root-table loads; bit 0: window 0, 1: middle, 2: top
+            const double2 w = ((SEAMD_ABL_NOTAB) & (C == 0 ? 1 : (C + 4 >= LOGN ? 4 : 2)))
+                                  ? make_double2(0.7 + idx * 1e-9, 0.7)
+                                  : *reinterpret_cast<const double2 *>(W + 2 * idx);
 #else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
 #endif
@@ -370,7 +372,8 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
             constexpr int g = decltype(gc)::value;
             const int idx   = N + ((8 >> b) - 1 + g) * (N / 16) + t;   // thread-major copy (se_types.h)
 #ifdef SEAMD_ABL_NOTAB
-            const double2 w = make_double2(0.7 + idx * 1e-9, 0.7);
+            const double2 w = ((SEAMD_ABL_NOTAB) & 1) ? make_double2(0.7 + idx * 1e-9, 0.7)
+                                                      : *reinterpret_cast<const double2 *>(W + 2 * idx);
 #else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
 #endif
@@ -459,7 +462,9 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
             // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
             const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
 #ifdef SEAMD_ABL_NOTAB
-            const uint2 rw  = make_uint2(12345u + idx, 54321u);
+            const uint2 rw  = ((SEAMD_ABL_NOTAB) & (C == 0 ? 1 : (C + 4 >= LOGN ? 4 : 2)))
+                                  ? make_uint2(12345u + idx, 54321u)
+                                  : *reinterpret_cast<const uint2 *>(RW + 2 * idx);
 #else
             const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
 #endif
