@@ -286,6 +286,10 @@ def kernel_source_hash():
         text = open(path, "r", encoding="utf-8", errors="replace").read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)       # block comments
         text = re.sub(r"//[^\n]*", " ", text)                    # line comments (no '//' inside literals here)
+        # timing-ablation hooks (-DSEAMD_ABL_*: builds with WRONG results, profiles/r03_ablation_transform.log)
+        # are not part of the product code: keep what the default build compiles
+        text = re.sub(r"#ifdef SEAMD_ABL_\w+\b((?:(?!#endif|#else).)*)#else(.*?)#endif", r"\2", text, flags=re.S)
+        text = re.sub(r"#ifdef SEAMD_ABL_\w+\b(?:(?!#endif|#else).)*#endif", " ", text, flags=re.S)
         h.update(os.path.basename(path).encode())
         h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
