@@ -239,3 +239,17 @@ def test_hot_kernels_keep_their_register_budget():
     for k in ("k_ntt_fuse<12, 0>", "k_ntt_fuse<14, 0>", "k_encode_rns<12, true>", "k_encode_rns<14, true>",
               "k_encode_encrypt<14, 0>", "k_encode_encrypt<14, 2>"):
         assert rows[k][1] == 0, (k, rows[k])
+    # the samplers: the batch form of the chain kernel at 160 VGPRs without spills (its per-lane-prime form must
+    # not leak into it), the staged kernels light enough to sit beside a transform workgroup
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "resource_usage.py"), "samplers"],
+                         capture_output=True, text=True, timeout=900).stdout
+    rows = {}
+    for line in out.splitlines()[1:]:
+        f = line.split()
+        if len(f) >= 6:
+            rows[" ".join(f[:-5]).replace("seamd::", "")] = (int(f[-5]), int(f[-3]), int(f[-2]))
+    assert rows["k_sample_uniform<12, 512, false>"][0] <= 168 and rows["k_sample_uniform<12, 512, false>"][1] == 0
+    assert rows["k_sample_uniform<14, 512, false>"][1] == 0
+    for k, vg in (("k_bulk_pair<14>", 80), ("k_bulk_pair<12>", 80), ("k_candidates", 80), ("k_resolve_light<14>", 40),
+                  ("k_sample_cbd", 80)):
+        assert rows[k][0] <= vg and rows[k][1] == 0, (k, rows[k])
