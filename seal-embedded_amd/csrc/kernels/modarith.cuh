@@ -31,6 +31,21 @@ __device__ __forceinline__ uint32_t barrett32(uint32_t x, uint32_t q, uint32_t c
     return csub(x - est * q, q);
 }
 
+// The reduction of an accepted sampler word (sample.c:50-56 reduces with barrett32).  Every accepted
+// word is below the rejection bound; for the 30-bit primes that bound is 4q - 1, so two conditional
+// subtractions (4 full-rate VALU ops) give the same residue as the mul_hi/mul_lo form (R4 = true).
+template <bool R4>
+__device__ __forceinline__ uint32_t reduce_sample(uint32_t x, uint32_t q, uint32_t cr_hi)
+{
+    if constexpr (R4)
+    {
+        x = min(x, x - 2u * q);
+        return min(x, x - q);
+    }
+    else
+        return barrett32(x, q, cr_hi);
+}
+
 // x mod q for a 64-bit x (modulo.h:84-116), ratio = floor(2^64/q) as (hi,lo).
 __device__ __forceinline__ uint32_t barrett64(uint64_t x, uint32_t q, uint32_t cr_hi, uint32_t cr_lo)
 {

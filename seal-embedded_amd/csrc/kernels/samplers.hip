@@ -16,6 +16,7 @@
 //   * ternary: 96-byte block per 96 coefficients, 1-byte redraw blocks interleaved between blocks.
 //   * CBD: counters are static (base + k), fully parallel.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../se_types.h"
 #include "kernel_args.h"
@@ -190,12 +191,14 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
             // word is reduce + compare + select-marker + shift the reject bit into a per-lane
             // mask; the masks are turned into reject-list entries once per step (a loop of
             // max-over-lanes popcount, ~3 iterations).
-            auto word = [&](uint32_t x, uint32_t &mask) -> uint32_t {
+            // (r4: every accepted word is below 4q, see reduce_sample; a rejected word's value is not used)
+            auto word = [&](auto r4, uint32_t x, uint32_t &mask) -> uint32_t {
                 const bool rej   = x >= bound;
-                const uint32_t r = barrett32(x, q, crh);
+                const uint32_t r = reduce_sample<decltype(r4)::value>(x, q, crh);
                 mask             = (mask << 1) | (rej ? 1u : 0u);
                 return rej ? kRejMarker : r;
             };
+            const bool red4 = !LANE_PRIME && (uint64_t)bound <= 4ull * q;   // uniform per prime
             // mask holds `count` words, word w of the step at bit (count - 1 - w); entries are
             // appended in ascending position order
             auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
@@ -234,14 +237,20 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
             {
                 keccak_f1600(st);
                 uint32_t m0 = 0, m1 = 0;  // words 0..31 / 32..33 of this step
+                auto emit = [&](auto r4) {
 #pragma unroll
-                for (int i = 0; i < 17; i++)
-                {
-                    uint32_t &mk = (i < 16) ? m0 : m1;
-                    uint32_t w0  = word(st.lo[i], mk);
-                    uint32_t w1  = word(st.hi[i], mk);
-                    *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-                }
+                    for (int i = 0; i < 17; i++)
+                    {
+                        uint32_t &mk = (i < 16) ? m0 : m1;
+                        uint32_t w0  = word(r4, st.lo[i], mk);
+                        uint32_t w1  = word(r4, st.hi[i], mk);
+                        *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                    }
+                };
+                if (red4)
+                    emit(std::true_type{});
+                else
+                    emit(std::false_type{});
                 if (__any((m0 | m1) != 0))
                 {
                     flush(m0, 32, idx);
@@ -257,8 +266,8 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
 #pragma unroll
                 for (int i = 0; i < TAIL_WORDS / 2; i++)
                 {
-                    uint32_t w0 = word(st.lo[i], m0);
-                    uint32_t w1 = word(st.hi[i], m0);
+                    uint32_t w0 = word(std::false_type{}, st.lo[i], m0);
+                    uint32_t w1 = word(std::false_type{}, st.hi[i], m0);
                     *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
                 }
                 flush(m0, TAIL_WORDS, idx);
@@ -573,9 +582,10 @@ __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
     KeccakHalf st;
     prng_absorb_half(st, seed, A.ctr_in ? A.ctr_in[b] : 0, part);
     uint32_t nrej = 0;   // maintained on the owner lane
+    const bool red4 = (uint64_t)bound <= 4ull * q;   // see reduce_sample
 
     // one squeeze step: word 2 i + part of the step comes from st.w[i]
-    auto emit = [&](uint32_t idx, int lanes64) {
+    auto emit = [&](auto r4, uint32_t idx, int lanes64) {
         uint32_t mask = 0;   // bit (31 - i): word i of this lane rejected
 #pragma unroll
         for (int i = 0; i < 17; i++)
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
             {
                 const uint32_t x = st.w[i];
                 const bool rej   = x >= bound;
-                const uint32_t r = barrett32(x, q, crh);
+                const uint32_t r = reduce_sample<decltype(r4)::value>(x, q, crh);
                 mask |= (rej ? 0x80000000u : 0u) >> i;
                 if (active) mypoly[idx + 2 * i + part] = rej ? kRejMarker : r;
             }
@@ -611,13 +621,16 @@ __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
     for (int step = 0; step < FULL_STEPS; step++)
     {
         keccak_half_f1600(st, part);
-        emit(idx, 17);
+        if (red4)
+            emit(std::true_type{}, idx, 17);
+        else
+            emit(std::false_type{}, idx, 17);
         idx += 34;
     }
     if constexpr (TAIL_WORDS > 0)
     {
         keccak_half_f1600(st, part);
-        emit(idx, TAIL_WORDS / 2);
+        emit(std::false_type{}, idx, TAIL_WORDS / 2);
     }
     if (active && part == 0) A.nrej[b] = nrej;
 }
