@@ -288,6 +288,9 @@ def kernel_source_hash():
         text = re.sub(r"//[^\n]*", " ", text)                    # line comments (no '//' inside literals here)
         # timing-ablation hooks (-DSEAMD_ABL_*: builds with WRONG results, profiles/r03_ablation_transform.log)
         # are not part of the product code: keep what the default build compiles
+        for m in re.finditer(r"#ifdef SEAMD_ABL_\w+\b(.*?)#endif", text, flags=re.S):
+            # the two patterns below do not nest: an #if inside an ablation block would change what is hashed
+            assert not re.search(r"#\s*if", m.group(1)), f"nested #if inside an SEAMD_ABL block of {path}"
         text = re.sub(r"#ifdef SEAMD_ABL_\w+\b((?:(?!#endif|#else).)*)#else(.*?)#endif", r"\2", text, flags=re.S)
         text = re.sub(r"#ifdef SEAMD_ABL_\w+\b(?:(?!#endif|#else).)*#endif", " ", text, flags=re.S)
         h.update(os.path.basename(path).encode())
@@ -343,11 +346,13 @@ def bench_values_device(B, n, dev, seed=0xC0FFEE, first=0):
 
 
 def cpu_baseline(n, npr, mode, budget_s=10.0):
-    """Reference CPU path on this box's host cores over a bounded sample of the same workload
+    """(budget: seconds of CPU work of the main sample; $SE_BENCH_CPU_BUDGET_S overrides -- the CPU tests use it)
+    Reference CPU path on this box's host cores over a bounded sample of the same workload
     (region = encode + sampler init + per-prime encrypt, keys resident; bench_sym.c:96-130,
     bench_asym.c; encode-only: ckks_encode_base + per prime reduce_set_pte + ntt_inpl)."""
     import vectors as V
     from oracle import pyoracle
+    budget_s = float(os.environ.get("SE_BENCH_CPU_BUDGET_S", budget_s))
     cores = pyoracle.host_threads()
     sk = V.secret_key(n)
     use_ref = pyoracle.ref_available()
@@ -388,7 +393,9 @@ def cpu_baseline(n, npr, mode, budget_s=10.0):
            else "oracle/se_oracle.c (C restatement, -O2)")
     return {"value": B / t, "unit": "ciphertexts/s" if mode != "encode" else "plaintexts/s",
             "cores": cores, "cpu": cpu_info(), "kind": "reference" if use_ref else "port",
-            "sample": f"{B} units of the same synthetic workload in {t:.2f} s on {cores} host thread(s); {src}",
+            "sample": f"{B} units of the same synthetic workload in {t:.2f} s on {cores} host thread(s) "
+                      f"[{pyoracle.host_threads_why()}]; {src}",
+            "per_thread_value": B / t / cores,
             "single_thread_value": one}
 
 
@@ -411,7 +418,7 @@ class Backend:
         else:
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-            ndev = torch.cuda.device_count()
+            ndev = self.ndev = torch.cuda.device_count()
             world_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
             # More local ranks than devices (a launcher asked for N ranks on a smaller box): ranks beyond
             # the device count stay idle, the others measure; coordination falls back to gloo (RCCL refuses
@@ -427,7 +434,11 @@ class Backend:
             self.num_cus = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
         self.local_rank = local_rank
         if self.stub:
-            self.oversubscribed = self.idle = False
+            # the stub pretends to have SE_BENCH_STUB_DEVICES devices, so that the idle-rank logic runs on CPU too
+            ndev = self.ndev = int(os.environ.get("SE_BENCH_STUB_DEVICES", "1024"))
+            world_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+            self.oversubscribed = world_local > ndev
+            self.idle = local_rank >= ndev
         # tensors of the timing collectives live where the process group's backend wants them
         self.coll_dev = self.dev if self.dist_backend == "nccl" else torch.device("cpu")
 
@@ -448,7 +459,129 @@ class Backend:
         return bench_values_device(B, n, self.dev, first=first)
 
 
-def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budget, want_gather, src_hash,
+class Collectives:
+    """Every collective of a run, in ONE place: working ranks and idle ranks (a launcher started more ranks than
+    the box has devices) go through the same methods in the same order, so the sequence cannot diverge.
+    `cold` is a gloo group beside the RCCL one: ranks that wait while rank 0 runs the CPU baseline block on a
+    socket there instead of spinning on a device collective (which would take host cores from the baseline)."""
+
+    def __init__(self, be, dist, world, cold=None):
+        self.be, self.dist, self.world, self.cold = be, dist, world, cold
+        self.on = dist is not None
+
+    def fence(self):
+        if not self.be.idle:
+            self.be.sync()
+        if self.on:
+            self.dist.barrier()
+        if not self.be.idle:
+            self.be.sync()
+
+    def timed(self, step, steps, warmup):
+        """The driver's contract: W untimed steps, then exactly K steps between two fences."""
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        return time.perf_counter() - t0
+
+    def exchange_times(self, elapsed, steps, device_name):
+        """Every rank's own time and device (the judge sees N ranks), then the contract's max over ranks."""
+        if not self.on:
+            return None, elapsed
+        torch, dist = self.be.torch, self.dist
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=self.be.coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        names = [None] * self.world
+        dist.all_gather_object(names, device_name)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.be.coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                 "ms_per_step": [t / steps * 1e3 if t > 0 else None for t in per_rank], "device": names}
+        return ranks, float(tmax.item())
+
+    def agree(self, code):
+        """Rank 0 decides (an int), everybody learns it."""
+        if not self.on:
+            return code
+        flag = self.be.torch.tensor([code], dtype=self.be.torch.int64, device=self.be.coll_dev)
+        self.dist.broadcast(flag, src=0)
+        return int(flag.item())
+
+    def max_seconds(self, sec):
+        if not self.on:
+            return sec
+        t = self.be.torch.tensor([sec], dtype=self.be.torch.float64, device=self.be.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_seconds(self, sec):
+        if not self.on:
+            return [sec]
+        mine = self.be.torch.tensor([sec], dtype=self.be.torch.float64, device=self.be.coll_dev)
+        every = [self.be.torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        return [float(t.item()) for t in every]
+
+    def cold_wait(self):
+        """Ranks other than 0 block here (on a socket) while rank 0 times the CPU reference."""
+        if self.on and self.world > 1:
+            self.dist.barrier(group=self.cold) if self.cold is not None else self.dist.barrier()
+
+
+def device_label(be):
+    """`cuda:i <name> <pci bus id>` of this rank's device (None in stub runs)."""
+    if be.stub or be.idle:
+        return None
+    pr = be.torch.cuda.get_device_properties(be.dev)
+    try:
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        bus = "?"
+    return f"cuda:{be.dev.index} {pr.name} pci={bus}"
+
+
+def verify_gather(be, ctx, mode, n, npr, B, world, c0_all, c1_all, seeds_all):
+    """Untimed check of the gathered slab on the root, no oracle involved: the path is deterministic, so the root
+    re-encrypts a few records of EVERY rank's block itself (same values / seeds, from `first = rank * B`) and
+    compares them with its slices of the gathered slab.  Returns (ok, records checked, first mismatch or None)."""
+    import numpy as np
+    import vectors as V
+    torch = be.torch
+    picks = sorted({0, 1, B // 2, B - 1} & set(range(B)))
+    gidx = [r * B + i for r in range(world) for i in picks]
+    k = len(gidx)
+    vals = torch.cat([be.values(1, n, g) for g in gidx], dim=0)
+    if mode != "encode":
+        pairs = [V.bench_seeds(1, first=g) for g in gidx]
+        ss = torch.from_numpy(np.concatenate([p[0] for p in pairs])).to(be.dev)
+        sd = torch.from_numpy(np.concatenate([p[1] for p in pairs])).to(be.dev)
+    a0 = torch.zeros((k, npr, n), dtype=torch.int32, device=be.dev)
+    a1 = torch.zeros_like(a0) if mode != "encode" else None
+    st = torch.zeros(k, dtype=torch.uint8, device=be.dev)
+    if mode == "sym":
+        ctx.encrypt_sym(vals, ss, sd, a0, a1, status=st)
+    elif mode == "asym":
+        ctx.encrypt_asym(vals, sd, a0, a1, status=st)
+    else:
+        ctx.encode_ntt(vals, a0, status=st)
+    be.sync()
+    for j, g in enumerate(gidx):
+        if not bool((c0_all[g] == a0[j]).all()):
+            return False, k, {"record": g, "rank": g // B, "slab": "c0"}
+        if c1_all is not None and not bool((c1_all[g] == a1[j]).all()):
+            return False, k, {"record": g, "rank": g // B, "slab": "c1"}
+        if seeds_all is not None and not bool((seeds_all[g] == ss[j]).all()):
+            return False, k, {"record": g, "rank": g // B, "slab": "share_seeds"}
+    return bool(st.all()), k, None
+
+
+def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budget, want_gather, src_hash,
                on_core=None):
     """One workload: timed region per the driver's contract, per-kernel profile, optional gather.
     `on_core(res)` is called with the contract fields + roofline as soon as they exist (before the gather
@@ -457,13 +590,19 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
     import vectors as V
     torch = be.torch
     n, npr, mode, _ = WORKLOADS[name]
-    use_dist = dist is not None
+    dist = coll.dist
+    use_dist = coll.on
     bpu = bytes_per_unit(mode, n, npr)
     if be.idle:
-        return run_idle(be, dist, steps, warmup)
+        # a rank without a device of its own: the same collectives in the same order (class Collectives), no work
+        coll.timed(lambda: None, steps, warmup)
+        coll.exchange_times(0.0, steps, None)
+        if want_cpu:
+            coll.cold_wait()
+        return {}
     active = world
     if be.oversubscribed:                            # only the ranks that own a device work
-        active = min(world, torch.cuda.device_count())
+        active = min(world, be.ndev)
         want_gather = False
     ctx = be.mod.Context(n, npr, be.dev.index if be.dev.type == "cuda" else be.local_rank)
     sk = V.secret_key(n)
@@ -509,9 +648,7 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
                     c0_all = c1_all = c1 = None
                     if not be.stub:
                         torch.cuda.empty_cache()
-        flag = torch.tensor([code], dtype=torch.int64, device=be.coll_dev)
-        dist.broadcast(flag, src=0)                 # the root decides for everybody
-        gather_plan = {0: None, 1: "full", 2: "seed-compressed"}[int(flag.item())]
+        gather_plan = {0: None, 1: "full", 2: "seed-compressed"}[coll.agree(code)]   # the root decides for everybody
     if gather_plan and rank == 0:
         c0 = c0_all[:B]                             # the root produces its block in place inside the slab
         if c1_all is not None:
@@ -529,38 +666,13 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         else:
             ctx.encode_ntt(vals, c0, status=status)
 
-    def fence():
-        be.sync()
-        if use_dist:
-            dist.barrier()
-        be.sync()
+    fence = coll.fence
 
     if os.environ.get("SE_BENCH_DEBUG_FLAGS"):          # A/B of pipeline shapes (tools/c4_ab.sh)
         ctx.set_debug_flags(int(os.environ["SE_BENCH_DEBUG_FLAGS"]))
     ctx.reserve(B)  # scratch allocation is not a step
-    for _ in range(warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ranks = None
-    if use_dist:
-        # every rank's own time (the judge sees N ranks), then the contract's max over ranks
-        mine = torch.tensor([elapsed], dtype=torch.float64, device=be.coll_dev)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank = [float(t.item()) for t in every]
-        names = [None] * world
-        dist.all_gather_object(names, None if be.stub else
-                               f"cuda:{be.dev.index} {torch.cuda.get_device_properties(be.dev).name}")
-        ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                 "ms_per_step": [t / steps * 1e3 if t > 0 else None for t in per_rank], "device": names}
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=be.coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = coll.timed(step, steps, warmup)
+    ranks, elapsed = coll.exchange_times(elapsed, steps, device_label(be))
     if not os.environ.get("SE_BENCH_SKIP_STATUS"):   # timing-only ablation builds produce garbage
         assert bool(status.all()), "an encode overflowed on synthetic data"
     ms_per_step = elapsed / steps * 1e3
@@ -683,51 +795,69 @@ def run_config(be, dist, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
             g0 = time.perf_counter()
             gather_records(c0, dist, dst=0, out=c0_all, sizes=sizes)
             moved = (world - 1) * B * rec_bytes
+            mine_bytes = B * rec_bytes
+            seeds_all = None
             if gather_plan == "full" and c1 is not None:
                 gather_records(c1, dist, dst=0, out=c1_all, sizes=sizes)
                 moved *= 2
+                mine_bytes *= 2
             elif gather_plan == "seed-compressed":
-                gather_records(ss, dist, dst=0, sizes=sizes)
+                seeds_all = gather_records(ss, dist, dst=0, sizes=sizes)
                 moved += (world - 1) * B * 64
+                mine_bytes += B * 64
+            be.sync()
+            own = time.perf_counter() - g0           # this rank's sends (root: all receives) are complete
             fence()
-            gsec = time.perf_counter() - g0
-            tg = torch.tensor([gsec], dtype=torch.float64, device=be.coll_dev)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            gsec = float(tg.item())
+            gsec = coll.max_seconds(time.perf_counter() - g0)
+            per_src = coll.all_seconds(own)
             if rank == 0 and os.environ.get("SE_BENCH_DUMP") and gather_plan == "full" and c1_all is not None:
                 import numpy as _np                    # test hook: the gathered slabs, rank order
                 _np.savez(os.environ["SE_BENCH_DUMP"], c0=c0_all.cpu().numpy(), c1=c1_all.cpu().numpy())
+            if rank == 0 and os.environ.get("SE_BENCH_TEST_CORRUPT_GATHER"):
+                c0_all[(world - 1) * B + B // 2, 0, 0] ^= 1     # test hook: a byte of the last rank's block lost
             gather = {"form": gather_plan, "ms": gsec * 1e3, "bytes_into_root": moved, "GB/s": moved / gsec / 1e9,
                       "value_with_gather": world * B / (ms_per_step * 1e-3 + gsec),
-                      "method": "batch_isend_irecv: every rank writes its block into its slice of the root's slab"}
+                      # each source's own block / the time until ITS sends had completed (rank 0: null)
+                      "per_source_GB/s": [None if r == 0 else mine_bytes / t / 1e9 if t > 0 else None
+                                          for r, t in enumerate(per_src)],
+                      "method": "batch_isend_irecv: every rank writes its block into its slice of the root's slab",
+                      "gather_verified": None}
+            res["gather"] = gather
+            # ---- untimed: did the bytes arrive?  The root re-encrypts records of every rank's block itself
+            if rank == 0:
+                try:
+                    good, k, bad = verify_gather(be, ctx, mode, n, npr, B, world, c0_all, c1_all, seeds_all)
+                    gather["gather_verified"] = bool(good)
+                    gather["verified_records"] = k
+                    gather["verified_how"] = ("root re-encrypted records 0, 1, B/2, B-1 of every rank's block from "
+                                              "the same synthetic inputs and compared them with its gathered slab")
+                    if bad:
+                        gather["first_mismatch"] = bad
+                except Exception as e:
+                    gather["gather_verified"] = False
+                    gather["verify_error"] = repr(e)
         except Exception as e:                      # the measurement above must survive a failed gather
-            gather = {"form": gather_plan, "error": repr(e)}
+            gather = {"form": gather_plan, "error": repr(e), "gather_verified": False}
     elif want_gather and use_dist and world > 1:
         gather = {"form": None, "skipped": "not enough free HBM on the root for the gathered slab"}
-
-    if want_cpu and rank == 0:
-        res["cpu_baseline"] = cpu_baseline(n, npr, mode, cpu_budget)
     if gather:
         res["gather"] = gather
+
+    if want_cpu:
+        # rank 0 times the reference on the host cores AFTER the timed region and the gather; the other ranks
+        # wait on a socket (Collectives.cold_wait) so that they do not take cores from it
+        if rank == 0:
+            try:
+                res["cpu_baseline"] = cpu_baseline(n, npr, mode, cpu_budget)
+            except Exception as e:
+                res["cpu_baseline"] = {"error": repr(e)}
+        coll.cold_wait()
     if hasattr(ctx, "close"):
         ctx.close()
     del vals, ss, sd, c0, c1, c0_all, c1_all, status
     if not be.stub:
         torch.cuda.empty_cache()
     return res
-
-
-def run_idle(be, dist, steps, warmup):
-    """A rank without a device of its own (more local ranks than GPUs): takes part in the job's collectives,
-    in the order run_config issues them, and contributes no work."""
-    torch = be.torch
-    dist.barrier()
-    dist.barrier()
-    mine = torch.zeros(1, dtype=torch.float64)
-    dist.all_gather([torch.zeros_like(mine) for _ in range(dist.get_world_size())], mine)
-    dist.all_gather_object([None] * dist.get_world_size(), None)
-    dist.all_reduce(mine, op=dist.ReduceOp.MAX)
-    return {}
 
 
 def main():
@@ -767,14 +897,20 @@ def main():
         else:
             dist.init_process_group(be.dist_backend, device_id=be.dev)
 
+    cold = None
+    if dist is not None and world > 1 and dist.get_backend() != "gloo":
+        cold = dist.new_group(backend="gloo")          # socket barrier for the ranks that wait on rank 0's CPU work
+    coll = Collectives(be, dist, world, cold)
     src_hash = kernel_source_hash()
-    want_cpu = world == 1 and not args.no_cpu_baseline
+    # N > 1 too: north_star wants the CPU reference "in the same run"; shorter sample there (the other ranks wait)
+    want_cpu = not args.no_cpu_baseline
     want_gather = world > 1 and not args.no_gather
     B = args.batch or WORKLOADS[args.workload][3]
     deadline = Deadline(rank)
     deadline_s = float(os.environ.get("SE_BENCH_DEADLINE_S", "600"))
-    line = run_config(be, dist, args.workload, B, args.steps, args.warmup, rank, world, want_cpu, 10.0,
-                      want_gather, src_hash, on_core=lambda res: deadline.arm(deadline_s, res))
+    line = run_config(be, coll, args.workload, B, args.steps, args.warmup, rank, world, want_cpu,
+                      10.0 if world == 1 else 6.0, want_gather, src_hash,
+                      on_core=lambda res: deadline.arm(deadline_s, res))
     if args.others is None:
         others = [] if args.workload != "c2" or args.batch else (["c3", "c4", "c5", "c1"] if world == 1 else ["c4"])
     else:
@@ -783,7 +919,7 @@ def main():
     for w in others:
         k = max(2, min(args.steps, 20))
         try:
-            r = run_config(be, dist, w, WORKLOADS[w][3], k, max(1, min(args.warmup, 4)), rank, world, want_cpu,
+            r = run_config(be, coll, w, WORKLOADS[w][3], k, max(1, min(args.warmup, 4)), rank, world, want_cpu,
                            4.0, want_gather, src_hash)
         except Exception as e:                          # never lose the top-level line to a further config
             r = {"config": {"workload": DESCR[w]}, "error": repr(e)}

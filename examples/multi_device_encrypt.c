@@ -8,6 +8,10 @@
  * per prime, per ciphertext; seal_embedded.c:196-203) -- which must not depend on how many devices the
  * batch was cut over -- and the rate of the call with everything resident.
  *
+ * The gathered slab is then CHECKED on the box: the root device encrypts the whole batch once more by itself
+ * (one context, one device, no peer copy) and the two slabs are compared word for word (gather_verified=1);
+ * `distinct_devices` says over how many different PCI devices the group really ran.
+ *
  *   gcc examples/multi_device_encrypt.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
  *       -Lseal-embedded_amd/lib -lseal_embedded_amd -L/opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/seal-embedded_amd/lib -o multi_device_encrypt
@@ -160,6 +164,57 @@ int main(int argc, char **argv)
             h = fnv(h, h0 + (b * nprimes + j) * n, n * 4);
             h = fnv(h, h1 + (b * nprimes + j) * n, n * 4);
         }
+    /* ---- did the bytes arrive?  One single-device pass over the whole batch on the root, compared word for word */
+    int gather_verified = 0;
+    size_t first_bad    = (size_t)-1;
+    {
+        se_amd_ctx *solo;
+        void *v, *s1, *s2;
+        uint32_t *r0, *r1;
+        const int rdev = se_amd_group_device(g, root);
+        CHECK_HIP(hipSetDevice(rdev));
+        CHECK_SE(se_amd_create(&solo, n, nprimes, rdev));
+        CHECK_SE(se_amd_set_secret_key(solo, sk));
+        CHECK_HIP(hipMalloc(&v, B * (n / 2) * sizeof(float)));
+        CHECK_HIP(hipMalloc(&s1, B * 64));
+        CHECK_HIP(hipMalloc(&s2, B * 64));
+        CHECK_HIP(hipMalloc((void **)&r0, B * rec * 4));
+        CHECK_HIP(hipMalloc((void **)&r1, B * rec * 4));
+        CHECK_HIP(hipMemcpy(v, values, B * (n / 2) * sizeof(float), hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(s1, share, B * 64, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(s2, seeds, B * 64, hipMemcpyHostToDevice));
+        CHECK_SE(se_amd_encrypt_sym_device(solo, (const float *)v, B, (const uint8_t *)s1, (const uint8_t *)s2, r0, r1,
+                                           NULL, NULL, NULL, NULL));
+        CHECK_HIP(hipDeviceSynchronize());
+        uint32_t *g0 = (uint32_t *)malloc(B * rec * 4), *g1 = (uint32_t *)malloc(B * rec * 4);
+        CHECK_HIP(hipMemcpy(g0, r0, B * rec * 4, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(g1, r1, B * rec * 4, hipMemcpyDeviceToHost));
+        gather_verified = 1;
+        for (size_t w = 0; w < B * rec; w++)
+            if (g0[w] != h0[w] || g1[w] != h1[w])
+            {
+                gather_verified = 0, first_bad = w / rec;
+                break;
+            }
+        free(g0), free(g1);
+        CHECK_HIP(hipFree(v));
+        CHECK_HIP(hipFree(s1));
+        CHECK_HIP(hipFree(s2));
+        CHECK_HIP(hipFree(r0));
+        CHECK_HIP(hipFree(r1));
+        se_amd_destroy(solo);
+    }
+    /* how many different PCI devices did the group span? */
+    size_t distinct = 0;
+    char bus[64][32];
+    for (size_t i = 0; i < ndev; i++)
+    {
+        char id[32] = "?";
+        (void)hipDeviceGetPCIBusId(id, (int)sizeof id, se_amd_group_device(g, i));
+        size_t k = 0;
+        while (k < distinct && strcmp(bus[k], id)) k++;
+        if (k == distinct) strcpy(bus[distinct++], id);
+    }
     int failed = 0;
     for (size_t i = 0; i < ndev; i++)
     {
@@ -169,9 +224,12 @@ int main(int argc, char **argv)
         for (size_t k = 0; k < count[i]; k++) failed += st[k] != 1;
         free(st);
     }
-    printf("failed=%d B=%zu devices=%zu all=%016llx seconds_with_gather=%.4f ct_per_s_with_gather=%.0f "
-           "seconds_resident=%.4f ct_per_s_resident=%.0f\n",
-           failed, B, ndev, (unsigned long long)h, sec, (double)B / sec, sec_res, (double)B / sec_res);
+    printf("failed=%d B=%zu devices=%zu distinct_devices=%zu gather_verified=%d all=%016llx seconds_with_gather=%.4f "
+           "ct_per_s_with_gather=%.0f seconds_resident=%.4f ct_per_s_resident=%.0f\n",
+           failed, B, ndev, distinct, gather_verified, (unsigned long long)h, sec, (double)B / sec, sec_res,
+           (double)B / sec_res);
+    if (!gather_verified)
+        fprintf(stderr, "gathered slab differs from the single-device pass at record %zu\n", first_bad);
     se_amd_group_destroy(g);
-    return failed == 0 ? 0 : 1;
+    return failed == 0 && gather_verified ? 0 : 1;
 }

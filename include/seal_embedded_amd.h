@@ -344,6 +344,11 @@ int se_amd_stage_ms(se_amd_ctx *ctx, float *ms /*[SE_AMD_STAGE_COUNT]*/,
 int se_amd_host_tables(size_t degree, size_t nprimes, uint32_t *q, uint32_t *const_ratio,
                        double *scale, uint16_t *index_map, double *ifft_w, uint32_t *ntt_rw,
                        uint32_t *intt_rw);
+/* SHA-256 (64 hex digits + NUL) of the IFFT root table this context's kernels read, copied back from the device:
+ * W[t] = (cos, -sin) of 2*pi*bitrev(t)/2n for t = 0 .. n-1 as little-endian doubles -- the digest SURVEY.md 8(c)
+ * trap T8 lists per n (fft.c:39-45: the roots are the HOST libm's; goldens generated on another libm may differ
+ * in rare last-bit cases).  Start-up check on the box that runs the kernels (__graft_entry__.smoke()). */
+int se_amd_ifft_table_sha256(se_amd_ctx *ctx, char out_hex[65]);
 int se_amd_set_reject_list_capacity(se_amd_ctx *ctx, uint32_t cap);
 /* test hook: redraw candidates the helper waves precompute per ciphertext (default n/32); tiny
  * values force the pooled fallback for the remaining draws. */

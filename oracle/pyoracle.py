@@ -376,6 +376,28 @@ def host_threads():
     return cores
 
 
+def host_threads_why():
+    """Why host_threads() is what it is, for the bench line: affinity mask, cgroup quota, hardware threads."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except Exception:
+        pass
+    hw = os.cpu_count() or aff
+    t = host_threads()
+    if quota is not None and t < aff:
+        return f"{t} = cgroup CPU quota ({quota:g} CPUs) of this process on a box with {hw} hardware threads"
+    if aff < hw:
+        return f"{t} = affinity mask of this process ({aff} of {hw} hardware threads)"
+    return f"{t} = all {hw} hardware threads of the box"
+
+
 def fnv1a64(data, h=0):
     L = Oracle.lib()
     b = np.frombuffer(bytes(data), dtype=np.uint8)

@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = (
     "se_amd_group_create", "se_amd_group_destroy", "se_amd_group_size", "se_amd_group_ctx", "se_amd_group_device",
     "se_amd_group_partition", "se_amd_group_set_secret_key", "se_amd_group_set_public_key", "se_amd_group_reserve",
     "se_amd_encrypt_sym_multi_device", "se_amd_encrypt_asym_multi_device", "se_amd_encode_ntt_multi_device",
-    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_set_asym_chunks", "se_amd_last_error", "se_amd_version",
+    "se_amd_set_reject_list_capacity", "se_amd_set_speculation_capacity", "se_amd_set_host_chunk", "se_amd_host_tables", "se_amd_ifft_table_sha256", "se_amd_reserve", "se_amd_set_debug_flags", "se_amd_set_pipeline", "se_amd_set_asym_chunks", "se_amd_last_error", "se_amd_version",
 )
 
 
@@ -124,6 +124,7 @@ def lib():
     L.se_amd_set_speculation_capacity.argtypes = [vp, u32]
     L.se_amd_set_host_chunk.argtypes = [vp, sz]
     L.se_amd_host_tables.argtypes = [sz, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.se_amd_ifft_table_sha256.argtypes = [vp, C.c_char_p]
     L.se_amd_reserve.argtypes = [vp, sz]
     L.se_amd_set_debug_flags.argtypes = [vp, u32]
     L.se_amd_set_pipeline.argtypes = [vp, i32, i32]
@@ -279,6 +280,12 @@ class Context:
         m = np.zeros(self.n, dtype=np.uint16)
         _check(self.L.se_amd_index_map(self.h, _ptr(m)), "se_amd_index_map")
         return m
+
+    def ifft_table_sha256(self):
+        """SHA-256 of the IFFT root table as the DEVICE holds it (SURVEY trap T8)."""
+        buf = C.create_string_buffer(65)
+        _check(self.L.se_amd_ifft_table_sha256(self.h, buf), "se_amd_ifft_table_sha256")
+        return buf.value.decode()
 
     def set_secret_key(self, sk_packed):
         import numpy as np

@@ -17,6 +17,7 @@
 #include "../../include/seal_embedded_amd.h"
 #include "se_context.h"
 #include "se_hostpipe.h"
+#include "se_sha256.h"
 
 namespace seamd {
 const std::string &last_error();
@@ -330,6 +331,21 @@ int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags)
 {
     if (!ctx) return SE_ERR_INVALD_ARGUMENT;
     ctx->c.debug_flags = flags;
+    return SE_SUCCESS;
+}
+
+int se_amd_ifft_table_sha256(se_amd_ctx *ctx, char out_hex[65])
+{
+    if (!ctx || !out_hex) return SE_ERR_INVALD_ARGUMENT;
+    // the table the kernels read, copied back from the DEVICE: W[t] = (re, im), t = 0 .. n-1, little-endian doubles
+    const size_t n = ctx->c.hp.n;
+    std::vector<double> w(2 * n);
+    SEAMD_HIP(hipSetDevice(ctx->c.device));
+    SEAMD_HIP(hipMemcpy(w.data(), ctx->c.dt.ifft_w, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+    seamd::Sha256 h;
+    h.update(w.data(), 2 * n * sizeof(double));
+    const std::string hex = h.hex();
+    memcpy(out_hex, hex.c_str(), 65);
     return SE_SUCCESS;
 }
 

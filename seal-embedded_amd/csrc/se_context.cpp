@@ -47,6 +47,13 @@ struct DevTemp
 };
 }  // namespace
 
+// Zero a device slab that held secret-dependent data before it is freed (best effort: errors are ignored, the
+// free follows either way).
+static void wipe_device(void *p, size_t bytes)
+{
+    if (p && bytes) (void)hipMemset(p, 0, bytes);
+}
+
 int hip_fail(hipError_t e, const char *what)
 {
     char buf[512];
@@ -76,6 +83,15 @@ Context::~Context()
     if (cand_stream) (void)hipStreamDestroy(cand_stream);
     for (auto &e : ev_cand)
         if (e) (void)hipEventDestroy(e);
+    // secret-bearing slabs are zeroed before they go back to the allocator: NTT(s), the error polynomials
+    // e / e0|e1, the ternary u, the per-ciphertext seeds of the speculation path and `a` (recomputable from the
+    // shareable seed, kept out of freed memory all the same)
+    const size_t n = hp.n, np = hp.nprimes;
+    wipe_device(d_s_hat, 2 * np * n * sizeof(uint32_t));
+    wipe_device(d_err, scratch_cap * 2 * n);
+    wipe_device(d_ucodes, scratch_cap * n);
+    wipe_device(d_sp_seeds, sp_cap * 64);
+    wipe_device(d_a, a_cap * np * n * sizeof(uint32_t));
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
                     d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general, d_compact,
                     d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail, d_sp_prime, d_nrej};
@@ -107,6 +123,17 @@ int Context::init(size_t n, size_t nprimes, int dev)
     if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
         num_cus <= 0)
         num_cus = 256;
+    // SE_AMD_NUM_CUS=<k>: plan launches as if the device had k CUs (a CPX / partial partition seen from the
+    // dispatch logic; tests of the small-device limits).  Never more than the device has.
+    if (const char *e = getenv("SE_AMD_NUM_CUS"))
+    {
+        const int k = atoi(e);
+        if (k > 0 && k < num_cus) num_cus = k;
+    }
+    // SE_AMD_STAGED=0|1 / SE_AMD_SPECULATION=0|1: override the form the dispatch would pick (the thresholds were
+    // measured on one 256-CU MI355X and are scaled by the CU count; results are bit-identical either way)
+    if (const char *e = getenv("SE_AMD_STAGED")) debug_flags |= atoi(e) ? 512u : 1024u;
+    if (const char *e = getenv("SE_AMD_SPECULATION")) spec_mode = atoi(e) ? 1 : 0;
     dp         = to_dev_params(hp);
     dp.num_cus = (uint32_t)num_cus;
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
@@ -223,6 +250,8 @@ int Context::ensure_scratch(size_t B, size_t rows)
     const size_t n = hp.n;
     if (B > scratch_cap)
     {
+        wipe_device(d_err, scratch_cap * 2 * n);      // e / e0|e1 and u of earlier calls
+        wipe_device(d_ucodes, scratch_cap * n);
         void *old[] = {d_err, d_ucodes, d_ctr, d_compact, d_nrej};
         for (void *p : old)
             if (p) (void)hipFree(p);
@@ -520,6 +549,7 @@ int Context::encrypt_sym_seeded(const float *d_values, size_t B, const uint8_t *
     if (B > a_cap)
     {
         SEAMD_HIP(hipDeviceSynchronize());   // earlier calls may still read the old slab
+        wipe_device(d_a, a_cap * hp.nprimes * hp.n * sizeof(uint32_t));
         if (d_a) (void)hipFree(d_a);
         d_a   = nullptr;
         a_cap = 0;
@@ -753,6 +783,11 @@ bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
         if (off * hp.n * sizeof(uint32_t) > small_bytes) return false;  // scratch rows bounded in bytes
     }
     plan.total = (uint32_t)off;
+    // All guesses are ONE launch (UniformArgs::prime_of).  Beyond the wave form's limit that launch takes the
+    // lane form, whose per-lane-prime instantiation exists for workgroups of up to 8 waves = 512 ciphertexts per
+    // CU: a fan-out wider than that (small devices / partitions: fewer than 128 CUs at the default small_limit)
+    // is not planned at all and the call takes the ordinary per-prime chain.
+    if ((uint64_t)B + off > (uint64_t)512 * (uint64_t)num_cus) return false;
     return true;
 }
 
@@ -766,10 +801,13 @@ bool Context::small_batch_plan(size_t B, SpecPlan &plan) const
 // the plain form runs np chains in sequence, B wide.
 bool Context::speculation_pays(size_t B, const SpecPlan &plan) const
 {
+    if (spec_mode >= 0) return spec_mode != 0;          // SE_AMD_SPECULATION
     const double steps = (double)((hp.n * 4 + 135) / 136);
+    // measured on 256 CUs: flat up to one wave per CU, then + 1.2 us per further wave per SIMD (4 per CU)
+    const double cus = (double)num_cus;
     auto perm_us = [&](size_t cts) {
         if (cts > uniform_wave_limit((unsigned)num_cus) || (debug_flags & 32)) return 10.7;
-        return 3.3 + 1.2 * (cts > 256 ? (double)(cts - 256) / 1024.0 : 0.0);
+        return 3.3 + 1.2 * ((double)cts > cus ? ((double)cts - cus) / (4.0 * cus) : 0.0);
     };
     const double spec  = steps * perm_us(B + plan.total);
     const double plain = (double)hp.nprimes * steps * perm_us(B);
@@ -790,6 +828,7 @@ int Context::encrypt_sym_small(const SpecPlan &plan, const float *d_values, cons
     if (total > sp_cap)
     {
         SEAMD_HIP(hipDeviceSynchronize());
+        wipe_device(d_sp_seeds, sp_cap * 64);
         void *old[] = {d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_prime};
         for (void *p : old)
             if (p) (void)hipFree(p);

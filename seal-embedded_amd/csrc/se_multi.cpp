@@ -18,6 +18,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -30,11 +34,70 @@ namespace seamd {
 const std::string &last_error();
 }
 
+namespace {
+
+// A host thread that lives as long as the group and runs one member's share of every call (creating a
+// std::thread per device and call cost tens of microseconds on small-batch group calls).
+class Worker
+{
+public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void submit(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            job_ = std::move(job), busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return !busy_; });
+    }
+
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;)
+        {
+            cv_.wait(l, [this] { return quit_ || (busy_ && job_); });
+            if (quit_) return;
+            std::function<void()> job = std::move(job_);
+            job_                      = nullptr;
+            l.unlock();
+            job();
+            l.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread th_;   // last: the thread starts when every other member is constructed
+};
+
+}  // namespace
+
 struct se_amd_group
 {
     std::vector<se_amd_ctx *> ctx;
     std::vector<int> device;
     std::vector<hipStream_t> stream;   // one per member, created on that member's device
+    std::vector<std::unique_ptr<Worker>> worker;   // members 1 .. ndev-1 (member 0 runs on the calling thread)
+    std::mutex call;                               // one multi-device call at a time per group
 };
 
 namespace {
@@ -73,6 +136,14 @@ int run_member(se_amd_group *g, size_t i, Mode mode, size_t B, const float *cons
     hipStream_t st    = g->stream[i];
     int rc            = hip_rc(hipSetDevice(g->device[i]), "hipSetDevice", err);
     if (rc) return rc;
+    // Whatever happens below, this member's stream is drained before the call returns: the caller may free or
+    // reuse its buffers (and the root's slab) the moment it has the return code.  The first error is kept.
+    auto finish = [&](int first_rc) {
+        std::string sync_err;
+        const int src = hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize", sync_err);
+        if (first_rc == SE_SUCCESS && src != SE_SUCCESS) err = sync_err;
+        return first_rc != SE_SUCCESS ? first_rc : src;
+    };
     if (blk.count)
     {
         uint8_t *status = d_status ? d_status[i] : nullptr;
@@ -95,7 +166,7 @@ int run_member(se_amd_group *g, size_t i, Mode mode, size_t B, const float *cons
         if (rc != SE_SUCCESS)
         {
             err = se_amd_last_error();   // thread-local: carried to the calling thread
-            return rc;
+            return finish(rc);
         }
         if (gather_root >= 0)
         {
@@ -108,7 +179,7 @@ int run_member(se_amd_group *g, size_t i, Mode mode, size_t B, const float *cons
             {
                 rc = hip_rc(hipMemcpyPeerAsync(dst0, root, d_c0[i], g->device[i], bytes, st), "hipMemcpyPeerAsync(c0)",
                             err);
-                if (rc) return rc;
+                if (rc) return finish(rc);
             }
             if (d_c1_all && c1)
             {
@@ -117,12 +188,12 @@ int run_member(se_amd_group *g, size_t i, Mode mode, size_t B, const float *cons
                 {
                     rc = hip_rc(hipMemcpyPeerAsync(dst1, root, c1, g->device[i], bytes, st), "hipMemcpyPeerAsync(c1)",
                                 err);
-                    if (rc) return rc;
+                    if (rc) return finish(rc);
                 }
             }
         }
     }
-    return hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize", err);
+    return finish(SE_SUCCESS);
 }
 
 int run_group(se_amd_group *g, Mode mode, size_t B, const float *const *d_values,
@@ -154,17 +225,17 @@ int run_group(se_amd_group *g, Mode mode, size_t B, const float *const *d_values
             return SE_ERR_INVALD_ARGUMENT;
         }
     }
+    std::lock_guard<std::mutex> one_call(g->call);
     std::vector<int> rcs(ndev, SE_SUCCESS);
     std::vector<std::string> errs(ndev);
-    std::vector<std::thread> workers;
     for (size_t i = 1; i < ndev; i++)
-        workers.emplace_back([&, i] {
+        g->worker[i - 1]->submit([&, i] {
             rcs[i] = run_member(g, i, mode, B, d_values, d_share_seeds, d_seeds, d_c0, d_c1, d_status, gather_root,
                                 d_c0_all, d_c1_all, errs[i]);
         });
     rcs[0] = run_member(g, 0, mode, B, d_values, d_share_seeds, d_seeds, d_c0, d_c1, d_status, gather_root, d_c0_all,
                         d_c1_all, errs[0]);
-    for (auto &w : workers) w.join();
+    for (auto &w : g->worker) w->wait();   // every member has drained its stream (run_member), error or not
     for (size_t i = 0; i < ndev; i++)
         if (rcs[i] != SE_SUCCESS)
         {
@@ -227,6 +298,7 @@ int se_amd_group_create(se_amd_group **out, size_t degree, size_t nprimes, const
                     (void)hipDeviceEnablePeerAccess(list[j], 0);
                 (void)hipGetLastError();
             }
+    for (size_t i = 1; i < list.size(); i++) g->worker.emplace_back(new Worker());
     *out = g;
     return SE_SUCCESS;
 }
@@ -234,6 +306,7 @@ int se_amd_group_create(se_amd_group **out, size_t degree, size_t nprimes, const
 void se_amd_group_destroy(se_amd_group *g)
 {
     if (!g) return;
+    g->worker.clear();   // joins the member threads
     for (size_t i = 0; i < g->ctx.size(); i++)
     {
         if (g->stream[i] && hipSetDevice(g->device[i]) == hipSuccess) (void)hipStreamDestroy(g->stream[i]);

@@ -47,6 +47,30 @@ def seeds_np(B, tag):
     return V.derive_seeds(tag, B)
 
 
+# --------------------------------------------------------------------------- SURVEY trap T8 on the GPU box
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+def test_t8_root_tables_on_this_box(env, golden, n):
+    """SURVEY 8(c) T8 asks for the twiddle digests to be recomputed "at start-up on the GPU box": the IFFT roots
+    are cos/sin of the HOST libm (fft.c:39-45), so the box that runs the kernels is the one whose libm counts.
+    Three tables must carry the committed digest here: the oracle's (this host's libm), the product's host table
+    (se_amd_host_tables) and the table the DEVICE holds (copied back and hashed by se_amd_ifft_table_sha256)."""
+    from oracle.pyoracle import Oracle
+    want = golden["digests"]["ifft_twiddle_sha256"][str(n)]
+    assert hashlib.sha256(Oracle(n, 1).twiddles().astype("<f8").tobytes()).hexdigest() == want
+    t = env["pkg"].host_tables(n, 1)
+    assert hashlib.sha256(t["ifft_w"].astype("<f8").tobytes()).hexdigest() == want
+    ctx = env["pkg"].Context(n, 1)
+    assert ctx.ifft_table_sha256() == want
+    ctx.close()
+
+
+def test_t8_host_tables_match_oracle_on_this_box(env):
+    """The CPU-suite check of every setup-time table (tests/test_cabi.py) repeated where the product runs."""
+    import test_cabi
+    for shape in [(1024, 1), (4096, 3), (16384, 13)]:
+        test_cabi.test_host_tables_match_oracle_and_golden(env["pkg"], shape)
+
+
 # --------------------------------------------------------------------------- PRNG / Keccak
 def test_prng_blocks_match_hashlib(env):
     torch = env["torch"]
@@ -901,6 +925,36 @@ def test_small_batch_prime_speculation(env, n, npr, B):
                 assert (r["ntt_pte"][b] == exp[b]["ntt_pte"]).all() and (r["pte"][b] == exp[b]["pte"]).all()
 
 
+@pytest.mark.parametrize("cus,spec,staged,B", [("16", None, None, 8), ("16", "1", None, 2), ("32", "0", None, 3),
+                                               ("16", None, "1", 300), ("64", None, "0", 1100)])
+def test_small_device_dispatch_limits(env, monkeypatch, cus, spec, staged, B):
+    """The dispatch on a device / partition with few CUs (SE_AMD_NUM_CUS plans launches as if the device had k
+    CUs) and under the form overrides SE_AMD_SPECULATION / SE_AMD_STAGED.  Round-3 advisor finding: with 16 CUs
+    the guesses of 8 ciphertexts at n = 8192 x 6 (about 1 200 virtual ciphertexts each) exceed the 512 per CU the
+    lane form's per-lane-prime instantiation serves; the plan is refused now (the call used to fail with
+    hipErrorInvalidValue) and the ordinary per-prime chain runs.  Bit-exact vs the oracle in every case."""
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("SE_AMD_NUM_CUS", cus)
+    if spec is not None:
+        monkeypatch.setenv("SE_AMD_SPECULATION", spec)
+    if staged is not None:
+        monkeypatch.setenv("SE_AMD_STAGED", staged)
+    n, npr = (8192, 6) if B <= 8 else (1024, 1)
+    ctx = env["pkg"].Context(n, npr)
+    sk = V.secret_key(n, seed=3)
+    ctx.set_secret_key(sk)
+    o = Oracle(n, npr)
+    vals = V.bench_values(B, n, first=5)
+    ss, sd = V.bench_seeds(B, first=77)
+    for rep in range(2):
+        r = ctx.encrypt_sym_host(vals, ss, sd)
+        assert r["failed"] == 0
+        for b in sorted({0, 1, B // 2, B - 1} & set(range(B))):
+            e = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+            assert (r["c0"][b] == e["c0"]).all() and (r["c1"][b] == e["c1"]).all(), (rep, b)
+    ctx.close()
+
+
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 129])
 def test_ragged_batch_sizes(env, B):
     from oracle.pyoracle import Oracle
@@ -1431,6 +1485,8 @@ def test_c_caller_of_multi_device_entry(env, tmp_path, devices, B):
                          text=True, timeout=300)
     kv = dict(f.split("=") for f in [l for l in res.stdout.splitlines() if l.startswith("failed=")][-1].split())
     assert kv["failed"] == "0" and int(kv["devices"]) == len(devices.split(","))
+    # the program compared the gathered slab with one single-device pass over the whole batch itself
+    assert kv["gather_verified"] == "1" and kv["distinct_devices"] == "1"
     o = Oracle(n, npr)
     h = 0xcbf29ce484222325
     for b in range(B):

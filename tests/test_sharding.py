@@ -116,6 +116,7 @@ def _run_bench(world, extra, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, SE_BENCH_STUB="stub_context", PYTHONPATH=os.path.join(root, "tests"))
+    env.setdefault("SE_BENCH_CPU_BUDGET_S", "0.4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", str(world)] + extra
@@ -136,10 +137,55 @@ def test_bench_rank_logic_two_ranks_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["batch_per_gpu"] == 3 and d["config"]["global_batch"] == 6
     assert abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6     # units of ALL ranks / max time
-    assert d["cpu_baseline"] is None and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True
+    # N > 1 lines carry the CPU reference too (north_star: "in the same run"), timed by rank 0 after the gather
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and "host thread" in cb["sample"]
     g = d["gather"]
     assert g["form"] == "full" and g["bytes_into_root"] == 2 * 3 * 4 * 1024 and g["value_with_gather"] < d["value"]
+    # the gathered slab was CHECKED on the root (records of every rank's block re-encrypted locally)
+    assert g["gather_verified"] is True and g["verified_records"] == 2 * 3 and "first_mismatch" not in g
+    assert g["per_source_GB/s"][0] is None and g["per_source_GB/s"][1] > 0
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None
+    assert d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo" and len(d["ranks"]["device"]) == 2
+
+
+def test_bench_flags_a_gather_that_lost_bytes(tmp_path):
+    """One word of the last rank's block flipped in the root's slab after the gather (test hook): the line
+    still carries the measurement, `gather_verified` is false and names the record."""
+    os.environ["SE_BENCH_TEST_CORRUPT_GATHER"] = "1"
+    try:
+        d = _run_bench(2, ["--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "4", "--others", "none",
+                           "--no-cpu-baseline"], tmp_path)
+    finally:
+        os.environ.pop("SE_BENCH_TEST_CORRUPT_GATHER", None)
+    g = d["gather"]
+    assert d["value"] > 0 and g["gather_verified"] is False
+    assert g["first_mismatch"] == {"record": 4 + 2, "rank": 1, "slab": "c0"}
+    assert d["cpu_baseline"] is None                     # --no-cpu-baseline
+
+
+def test_bench_three_ranks_seed_and_encode_forms(tmp_path):
+    """Three ranks, encode-only workload (one slab): gather verified for every rank's block."""
+    d = _run_bench(3, ["--steps", "1", "--warmup", "1", "--workload", "c5", "--batch", "2", "--others", "none",
+                       "--no-cpu-baseline"], tmp_path)
+    assert d["n_gpus"] == 3 and d["gather"]["gather_verified"] is True and d["gather"]["verified_records"] == 6
+
+
+def test_launcher_with_more_ranks_than_devices(tmp_path):
+    """torch.distributed.run started 2 ranks on a box that shows ONE device: rank 1 idles through the same
+    collective sequence (class Collectives), rank 0 measures, the line says what happened -- and still has its
+    CPU baseline (the idle rank waits for it)."""
+    os.environ["SE_BENCH_STUB_DEVICES"] = "1"
+    try:
+        d = _run_bench(2, ["--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "2", "--others", "c1"],
+                       tmp_path)
+    finally:
+        os.environ.pop("SE_BENCH_STUB_DEVICES", None)
+    assert d["n_gpus"] == 1 and d["requested_gpus"] == 2 and "only 1 device(s)" in d["note"]
+    assert d["config"]["global_batch"] == 2 and "gather" not in d
+    assert d["ranks"]["ms_per_step"][1] is None and d["cpu_baseline"]["value"] > 0
+    assert d["other_configs"][0]["value"] > 0
 
 
 def test_bench_gathered_slab_is_single_process_order(tmp_path):
@@ -184,6 +230,7 @@ def _run_bench_plain(extra, tmp_path, env_extra=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SE_BENCH_STUB="stub_context", PYTHONPATH=os.path.join(root, "tests"))
+    env.setdefault("SE_BENCH_CPU_BUDGET_S", "0.4")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     env.update(env_extra or {})
