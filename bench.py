@@ -54,6 +54,9 @@ WORKLOADS = {
     "c3": (4096, 3, "asym", 65536),
     "c4": (16384, 6, "sym", 32768),
     "c5": (4096, 3, "encode", 1048576),
+    # reference-supported shapes beyond BASELINE.json (optional: `--others x1,x2` or `--workload x1`)
+    "x1": (16384, 6, "asym", 16384),
+    "x2": (8192, 6, "sym", 32768),
 }
 DESCR = {
     "c1": "C1: n=1024, 1x27-bit prime, symmetric encode+encrypt",
@@ -61,6 +64,8 @@ DESCR = {
     "c3": "C3: n=4096, 3x30-bit RNS primes, asymmetric (pk) encode+encrypt",
     "c4": "C4: n=16384, 6x30-bit RNS primes, symmetric encode+encrypt",
     "c5": "C5: n=4096, 3x30-bit RNS primes, encode-only (IFFT + RNS reduce + NTT)",
+    "x1": "X1 (beyond BASELINE): n=16384, 6x30-bit RNS primes, asymmetric (pk) encode+encrypt",
+    "x2": "X2 (beyond BASELINE): n=8192, 6x30-bit RNS primes, symmetric encode+encrypt",
 }
 KERNEL_NAMES = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform", "ternary": "k_sample_ternary",
                 "encode_encrypt": "k_encode_encrypt", "encode_rns": "k_encode_rns", "ntt_fuse": "k_ntt_fuse"}
@@ -311,6 +316,26 @@ def load_profile(fname, workload, batch, src_hash):
         return {k: v for k, v in ent.items() if isinstance(v, dict) and v.get("batch") == batch}
     except Exception:
         return {}
+
+
+def load_valu_mix(src_hash):
+    """profiles/valu_mix.json (tools/valu_mix.py): mean issue cycles per VALU wave instruction of every kernel,
+    from the static mix of its hot loops weighted with the per-opcode issue rates tools/ubench2 measured on the
+    MI355X.  {} when it was built for other kernel sources."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
+            vm = json.load(f)
+        return vm if vm.get("_source_sha256") == src_hash else {}
+    except Exception:
+        return {}
+
+
+def kernel_cpi(vm, kernel, mode, logn):
+    ks = vm.get("kernels", {})
+    for key in (f"{kernel}@{mode}{logn}", f"{kernel}@{logn}", kernel):
+        if key in ks:
+            return ks[key]["cycles_per_inst"]
+    return None
 
 
 def bench_values_device(B, n, dev, seed=0xC0FFEE, first=0):
@@ -732,6 +757,31 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         insts = sum(stage_profile(sq, s, "valu_wave_insts_per_step") for s in used)
         simds = 4 * be.num_cus
         floor_ms = insts * 4.0 / simds / VALU_CLOCK_HZ * 1e3
+        # opcode-weighted bound: every kernel's dynamic instruction count x ITS mean issue cycles (v_xor / v_add /
+        # v_sub issue in ~2.4 cycles, v_bitop3 in ~3.5, the rest in 4: tools/ubench2, tools/valu_mix.py)
+        vm, weighted = load_valu_mix(src_hash), None
+        if vm:
+            logn, cyc, cpis, covered = n.bit_length() - 1, 0.0, {}, 0
+            for s in used:
+                for k in STAGE_KERNELS.get(s, (KERNEL_NAMES[s],)):
+                    if k not in sq:
+                        continue
+                    cpi = kernel_cpi(vm, k, mode, logn)
+                    ki = sq[k]["valu_wave_insts_per_step"]
+                    cyc += ki * (cpi if cpi is not None else 4.0)
+                    covered += ki if cpi is not None else 0
+                    if cpi is not None:
+                        cpis[k] = cpi
+            wf = cyc / simds / VALU_CLOCK_HZ * 1e3
+            weighted = {"floor_ms": wf, "frac": wf / ms_per_step,
+                        "floor_ms_at_sampled_clock": wf * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) if clock else None,
+                        "frac_at_sampled_clock": (wf * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) / ms_per_step
+                                                  if clock else None),
+                        "cycles_per_inst": cpis, "insts_covered": covered / insts if insts else None,
+                        "source": "profiles/valu_mix.json: static opcode mix of each kernel's hot loops (hipcc -S) x "
+                                  "per-opcode issue cycles measured by tools/ubench2 on this GPU model; single-opcode "
+                                  "streams reach these rates, a mixed Keccak stream measures ~10 % above this bound "
+                                  "(DESIGN.md section 5)"}
         valu = {"bound": "valu", "wave_insts_per_step": insts, "simds": simds, "clock_hz": VALU_CLOCK_HZ,
                 "floor_ms": floor_ms, "frac": floor_ms / ms_per_step,
                 # the same floor at the clock the chip actually sustained under this workload (sampled above)
@@ -739,6 +789,9 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
                 "floor_ms_at_sampled_clock": floor_ms * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) if clock else None,
                 "frac_at_sampled_clock": (floor_ms * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) / ms_per_step
                                           if clock else None),
+                "floor_ms_weighted": weighted["floor_ms"] if weighted else None,
+                "frac_weighted": weighted["frac"] if weighted else None,
+                "weighted": weighted,
                 "note": "wave64 VALU instruction = 4 SIMD cycles; floor = insts x 4 / SIMDs / clock (nominal 2.4 GHz; "
                         "the chip sustains 2.2-2.3 GHz under these loads, and v_xor/v_add/v_sub issue up to 1.7x "
                         "faster than 4 cycles, so the figure is an estimate of the issue bound, not a hard floor)"}

@@ -75,33 +75,75 @@ __device__ __forceinline__ void load16_pairs(uint32_t (&w)[16], uint32_t (&wp)[1
     }
 }
 
-// quad-layout (transform.cuh, tile_to_quads) accessors: every instruction of a wave covers 1 KiB contiguous
+// quad-layout (transform.cuh, tile_to_quads) accessors: every instruction of a wave covers 1 KiB contiguous.
+// One base pointer per access (the thread's first quad) and compile-time offsets that land in the instructions'
+// immediate fields.
+//
+// opaque_index(): a thread index the compiler must treat as freshly computed where it is taken.  The fused
+// kernels address the same per-thread pieces (a, key pairs, c0 / c1, u, e1) again for every prime; seen as
+// loop-invariant, the 64-bit ADDRESS of every piece was formed ahead of the prime loop and carried -- or
+// spilled -- across it (public-key form: 206 VGPRs, of which 44 were such addresses; the one-transform-at-a-
+// time form spilled 22 of them).  Global addresses inside the prime loop are formed from an opaque copy of the
+// thread index taken per iteration: a few 64-bit adds per prime, and the registers are free.
+__device__ __forceinline__ int opaque_index(int t)
+{
+    __asm__ volatile("" : "+v"(t));
+    return t;
+}
+
 __device__ __forceinline__ void load_quads(uint32_t (&v)[16], const uint32_t *poly, int t)
 {
+    const uint32_t *base = poly + quad_index(t, 0);
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
-        const uint4 w = *reinterpret_cast<const uint4 *>(poly + quad_index(t, i));
+        const uint4 w = *reinterpret_cast<const uint4 *>(base + (i << 8));
         v[4 * i] = w.x, v[4 * i + 1] = w.y, v[4 * i + 2] = w.z, v[4 * i + 3] = w.w;
     }
 }
 
 __device__ __forceinline__ void store_quads(uint32_t *poly, const uint32_t (&v)[16], int t)
 {
+    uint32_t *base = poly + quad_index(t, 0);
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        *reinterpret_cast<uint4 *>(poly + quad_index(t, i)) =
-            make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        *reinterpret_cast<uint4 *>(base + (i << 8)) = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+// Streaming forms (non-temporal: the data is touched once and should not displace lines other kernels are
+// still filling in L2) -- used by k_ntt_fuse under SEAMD_NTT_FUSE_NT (A/B of the staged sampler's write
+// amplification: its half-written lines of `a` are evicted by the transform kernel streaming beside it)
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_quads_nt(uint32_t (&v)[16], const uint32_t *poly, int t)
+{
+    const uint32_t *base = poly + quad_index(t, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const nt_u4 w = __builtin_nontemporal_load(reinterpret_cast<const nt_u4 *>(base + (i << 8)));
+        v[4 * i] = w.x, v[4 * i + 1] = w.y, v[4 * i + 2] = w.z, v[4 * i + 3] = w.w;
+    }
+}
+__device__ __forceinline__ void store_quads_nt(uint32_t *poly, const uint32_t (&v)[16], int t)
+{
+    uint32_t *base = poly + quad_index(t, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        nt_u4 w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        __builtin_nontemporal_store(w, reinterpret_cast<nt_u4 *>(base + (i << 8)));
+    }
 }
 
 // interleaved (value, shoup) pairs of one polynomial's table, quad layout
 __device__ __forceinline__ void load_quads_pairs(uint32_t (&w)[16], uint32_t (&wp)[16], const uint32_t *tab,
                                                  int t)
 {
+    const uint32_t *base = tab + 2 * (size_t)quad_index(t, 0);
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
-        const uint4 *p4 = reinterpret_cast<const uint4 *>(tab + 2 * (size_t)quad_index(t, i));
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(base + (i << 9));
         const uint4 a = p4[0], b = p4[1];
         w[4 * i] = a.x, wp[4 * i] = a.y, w[4 * i + 1] = a.z, wp[4 * i + 1] = a.w;
         w[4 * i + 2] = b.x, wp[4 * i + 2] = b.y, w[4 * i + 3] = b.z, wp[4 * i + 3] = b.w;
@@ -315,7 +357,11 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
 template <int MODE>
 constexpr int enc_quad_stride()
 {
+#ifdef SEAMD_ASYM_SERIAL4
+    return 20;
+#else
     return MODE == kModeAsym ? 28 : 20;
+#endif
 }
 
 template <int LOGN, int MODE, bool GENERAL>
@@ -324,7 +370,11 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 {
     const int t = thread_index<GENERAL>();
     using G            = XformGeom<LOGN>;
+#ifdef SEAMD_ASYM_SERIAL4
+    constexpr bool ASYM3 = false;       // A/B: one NTT at a time, one plane + transpose region, 4 workgroups per CU
+#else
     constexpr bool ASYM3 = LOGN <= 12;  // three-way NTT per prime (three LDS planes; spills at n = 8192)
+#endif
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
@@ -375,7 +425,16 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     // keeps the tile layout (three transposes beside the int64 plaintext spill).
     constexpr bool QUADS   = LOGN <= 12 && (MODE != kModeAsym || !GENERAL);
     constexpr int QSTRIDE  = enc_quad_stride<MODE>();
-    uint32_t *qlds         = lds32 + (MODE == kModeAsym ? 3 : 1) * G::SLOTS;
+    // The public-key form's transpose region lives INSIDE its three planes (free after the last exchange's
+    // trailing barrier; one workgroup barrier per prime keeps the next prime's first exchange off it): 51 KiB per
+    // workgroup instead of 79, THREE workgroups per CU -- possible since the kernel needs 150 VGPRs (opaque_index
+    // above; 206 before).  Fused stage 5.09 -> 4.83 ms per 65 536 (profiles/r04_ab_transform.log).
+#ifndef SEAMD_NO_ASYM3_ALIAS
+    constexpr bool QALIAS  = MODE == kModeAsym && ASYM3 && !GENERAL;
+#else
+    constexpr bool QALIAS  = false;
+#endif
+    uint32_t *qlds         = lds32 + (QALIAS ? 0 : (MODE == kModeAsym && ASYM3 ? 3 : 1)) * G::SLOTS;
     auto to_quads = [&](uint32_t (&v)[16]) {
         if constexpr (QUADS) tile_to_quads<QSTRIDE>(v, qlds, t);
     };
@@ -386,6 +445,11 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
         const uint32_t *RW = T.ntt_rw + 2 * xform_table_len(N) * j;
         const size_t pb    = (b * np + j) * N;            // this polynomial in the [ct][prime][coeff] slabs
         const size_t kb    = (size_t)2 * N * j;           // this prime's rows of the (value, shoup) key tables
+        // thread index for this prime's GLOBAL addresses (opaque_index above; the encode-only form has one store
+        // per prime and nothing to hoist: measured 1 % slower with it)
+        // (the transforms keep the plain index: with the opaque one the symmetric form needs 100 VGPRs instead of
+        // 120 but recomputes its LDS and root addresses per prime and runs 12 % slower, profiles/r04_ab_transform.log)
+        const int tg       = MODE == kModeEncodeOnly ? t : opaque_index(t);
         uint32_t x[16];
 
         if constexpr (MODE == kModeAsym && ASYM3)
@@ -394,12 +458,13 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             // (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1), NTT(e1) (:263-272) and
             // NTT(m + e0) (:280-284)
             uint32_t uh[16], y[16];
+            const int8_t *up = A.ucodes + b * N + tg, *ep = A.err + b * 2 * N + N + tg;
 #pragma unroll
             for (int e = 0; e < 16; e++)
             {
-                uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
+                uint32_t code = (uint32_t)up[e << CTOP];
                 uh[e]         = code + q - 1u;            // q-1, q, q+1 == -1, 0, 1 (sample.c:98-111 mod q)
-                int32_t e1    = A.err[b * 2 * N + N + (e << CTOP) + t];
+                int32_t e1    = ep[e << CTOP];
                 y[e]          = q + (uint32_t)e1;          // == reduce_set_e_small (ckks_common.c:259-265) mod q
             }
             reduce_signed16(m, x, q, crh, crl, small);
@@ -411,82 +476,97 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 #pragma unroll
                 for (int e = 0; e < 16; e++) y[e] = canon4(y[e], q, two_q);
                 to_quads(y);
-                ld_pairs<QUADS>(w, wp, T.pk1 + kb, t);
+                ld_pairs<QUADS>(w, wp, T.pk1 + kb, tg);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     y[e]        = csub(pr + y[e], q);
                 }
-                st_poly<QUADS>(A.c1 + pb, y, t);
+                st_poly<QUADS>(A.c1 + pb, y, tg);
             }
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             to_quads(x);
-            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, t);
+            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, tg);
             {
                 // c0 = pk0 . u_hat + NTT(m + e0)   (:255)
                 uint32_t w[16], wp[16], out[16];
-                ld_pairs<QUADS>(w, wp, T.pk0 + kb, t);
+                ld_pairs<QUADS>(w, wp, T.pk0 + kb, tg);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     out[e]      = csub(pr + x[e], q);
                 }
-                st_poly<QUADS>(A.c0 + pb, out, t);
+                st_poly<QUADS>(A.c0 + pb, out, tg);
             }
+            if constexpr (QALIAS) __syncthreads();
         }
         else if constexpr (MODE == kModeAsym)
         {
+            // one transform at a time (n >= 8192; n <= 4096 under SEAMD_ASYM_SERIAL4: quad-layout epilogues)
             // u_hat = NTT(expand(u))   (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1)
             uint32_t uh[16];
+            const int8_t *up = A.ucodes + b * N + tg;
 #pragma unroll
             for (int e = 0; e < 16; e++)
             {
-                uint32_t code = (uint32_t)A.ucodes[b * N + (e << CTOP) + t];
+                uint32_t code = (uint32_t)up[e << CTOP];
                 uh[e]         = code + q - 1u;
             }
             ntt_tiles<LOGN>(uh, RW, q, lds32, t);
+            to_quads(uh);
             // c1 = pk1 . u_hat + NTT(e1)   (:251, :263-272)
+            const int8_t *ep = A.err + b * 2 * N + N + tg;
 #pragma unroll
             for (int e = 0; e < 16; e++)
             {
-                int32_t e1 = A.err[b * 2 * N + N + (e << CTOP) + t];
+                int32_t e1 = ep[e << CTOP];
                 x[e]       = q + (uint32_t)e1;
             }
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+            to_quads(x);
             {
                 uint32_t w[16], wp[16], out[16];
-                ld_pairs<false>(w, wp, T.pk1 + kb, t);
+                ld_pairs<QUADS>(w, wp, T.pk1 + kb, tg);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
-                    out[e]      = csub(pr + canon4(x[e], q, two_q), q);
+                    out[e]      = csub(pr + x[e], q);
                 }
-                st_poly<false>(A.c1 + pb, out, t);
+                st_poly<QUADS>(A.c1 + pb, out, tg);
             }
             // c0 = pk0 . u_hat + NTT(m + e0)   (:255, :280-284)
             reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles<LOGN>(x, RW, q, lds32, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
-            if (A.ntt_pte) st_poly<false>(A.ntt_pte + pb, x, t);
+            to_quads(x);
+            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, tg);
             {
                 uint32_t w[16], wp[16], out[16];
-                ld_pairs<false>(w, wp, T.pk0 + kb, t);
+                ld_pairs<QUADS>(w, wp, T.pk0 + kb, tg);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
                     out[e]      = csub(pr + x[e], q);
                 }
-                st_poly<false>(A.c0 + pb, out, t);
+                st_poly<QUADS>(A.c0 + pb, out, tg);
             }
         }
         else
         {
+#ifndef SEAMD_NO_PREFETCH_A
+            // a_j comes from HBM: requested before the transform, it lands while the NTT runs (fused stage
+            // 2.60 -> 2.38 ms per 65 536, profiles/r04_ab_transform.log; 16 VGPRs the NTT phase has to spare)
+            uint32_t a_pre[16];
+            if constexpr (MODE == kModeSym && QUADS) ld_poly<QUADS>(a_pre, A.c1 + pb, tg);
+#endif
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
             reduce_signed16(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
                                                                           // symmetric kernel keeps the exact form
@@ -499,24 +579,32 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             to_quads(x);
-            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, t);
+            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, tg);
             if constexpr (MODE == kModeSym)
             {
                 // c0 = -(s_hat . a) + NTT(m+e)   (ckks_sym.c:273-300); a was written to c1
                 uint32_t a[16], w[16], wp[16], out[16];
-                ld_poly<QUADS>(a, A.c1 + pb, t);
-                ld_pairs<QUADS>(w, wp, T.s_hat + kb, t);
+#ifndef SEAMD_NO_PREFETCH_A
+                if constexpr (QUADS)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) a[e] = a_pre[e];
+                }
+                else
+#endif
+                ld_poly<QUADS>(a, A.c1 + pb, tg);
+                ld_pairs<QUADS>(w, wp, T.s_hat + kb, tg);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
                     uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
                     out[e]      = csub(x[e] + q - pr, q);
                 }
-                st_poly<QUADS>(A.c0 + pb, out, t);
+                st_poly<QUADS>(A.c0 + pb, out, tg);
             }
             else
             {
-                st_poly<QUADS>(A.c0 + pb, x, t);
+                st_poly<QUADS>(A.c0 + pb, x, tg);
             }
         }
     }
@@ -527,6 +615,12 @@ template <int LOGN, int MODE, bool GENERAL>
 constexpr int enc_blocks()
 {
     if (LOGN > 12) return 1;
+#ifdef SEAMD_ASYM_SERIAL4
+    if (MODE == kModeAsym) return GENERAL ? 2 : SEAMD_ASYM_SERIAL4;
+#endif
+#ifndef SEAMD_NO_ASYM3_ALIAS
+    if (MODE == kModeAsym && !GENERAL) return 3;   // transpose region inside the planes (encrypt_one, QALIAS)
+#endif
     if (MODE == kModeAsym) return 2;   // 3 (with the transpose region aliased) spills: 5.45 -> 7.07 ms
     return GENERAL ? 3 : 4;
 }
@@ -672,7 +766,11 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     const uint32_t bias = compact ? two_q : 0u;
     uint32_t x[16];
 #pragma unroll
+#ifdef SEAMD_NTT_FUSE_NT
+    for (int e = 0; e < 16; e++) x[e] = __builtin_nontemporal_load(src + (e << CTOP) + t) + bias;
+#else
     for (int e = 0; e < 16; e++) x[e] = src[(e << CTOP) + t] + bias;
+#endif
     // issue the epilogue operands now; they land while the NTT runs.  At n = 16384 only `a` (HBM) is
     // prefetched; the L2-resident s_hat pairs are fetched after the NTT to stay within 96 VGPRs.
     // All epilogue accesses are in quad layout (transform.cuh, tile_to_quads): 1 KiB contiguous per wave
@@ -681,7 +779,11 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     uint32_t a[16], w[16], wp[16];
     if constexpr (MODE == kModeSym)
     {
+#ifdef SEAMD_NTT_FUSE_NT
+        load_quads_nt(a, A.c1 + (b * np + j) * N, t);
+#else
         load_quads(a, A.c1 + (b * np + j) * N, t);
+#endif
         if constexpr (!LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
     }
     ntt_tiles<LOGN>(x, T.ntt_rw + 2 * xform_table_len(N) * j, q, lds32, t);
@@ -701,7 +803,11 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
             uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
             out[e]      = csub(x[e] + q - pr, q);
         }
+#ifdef SEAMD_NTT_FUSE_NT
+        store_quads_nt(poly, out, t);
+#else
         store_quads(poly, out, t);
+#endif
     }
     else
     {
@@ -909,8 +1015,16 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
     size_t shmem_fast = planes, shmem_gen = planes;
     if (LOGN <= 12)
     {
+#ifdef SEAMD_ASYM_SERIAL4
+        const size_t ntt_planes = (size_t)G::SLOTS * sizeof(uint32_t);
+#else
         const size_t ntt_planes = (size_t)(MODE == kModeAsym ? 3 : 1) * G::SLOTS * sizeof(uint32_t);
+#endif
+#ifndef SEAMD_NO_ASYM3_ALIAS
+        shmem_fast = MODE == kModeAsym ? std::max(planes, std::max(ntt_planes, quads)) : std::max(planes, ntt_planes + quads);
+#else
         shmem_fast = std::max(planes, ntt_planes + quads);
+#endif
         shmem_gen  = MODE == kModeAsym ? std::max(planes, ntt_planes) : shmem_fast;
     }
     hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);
