@@ -110,31 +110,6 @@ __device__ __forceinline__ void store_quads(uint32_t *poly, const uint32_t (&v)[
         *reinterpret_cast<uint4 *>(base + (i << 8)) = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
-// Streaming forms (non-temporal: the data is touched once and should not displace lines other kernels are
-// still filling in L2) -- used by k_ntt_fuse under SEAMD_NTT_FUSE_NT (A/B of the staged sampler's write
-// amplification: its half-written lines of `a` are evicted by the transform kernel streaming beside it)
-typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load_quads_nt(uint32_t (&v)[16], const uint32_t *poly, int t)
-{
-    const uint32_t *base = poly + quad_index(t, 0);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-        const nt_u4 w = __builtin_nontemporal_load(reinterpret_cast<const nt_u4 *>(base + (i << 8)));
-        v[4 * i] = w.x, v[4 * i + 1] = w.y, v[4 * i + 2] = w.z, v[4 * i + 3] = w.w;
-    }
-}
-__device__ __forceinline__ void store_quads_nt(uint32_t *poly, const uint32_t (&v)[16], int t)
-{
-    uint32_t *base = poly + quad_index(t, 0);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-        nt_u4 w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-        __builtin_nontemporal_store(w, reinterpret_cast<nt_u4 *>(base + (i << 8)));
-    }
-}
-
 // interleaved (value, shoup) pairs of one polynomial's table, quad layout
 __device__ __forceinline__ void load_quads_pairs(uint32_t (&w)[16], uint32_t (&wp)[16], const uint32_t *tab,
                                                  int t)
@@ -421,7 +396,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     // NTT plane(s), so it needs no barrier against the next prime's exchanges.  Symmetric / encode-only:
     // rows of 20 words (32 conflict cycles per transpose instead of the 16 of 28-word rows,
     // tools/lds_conflicts.py) keep plane + region at 37 KiB -- 4 workgroups per CU.  Public-key form: rows
-    // of 28 behind the three planes (register-bound at 2 workgroups per CU either way); its general form
+    // of 28 INSIDE the three planes (QALIAS below: 51 KiB, 3 workgroups per CU at 150 VGPRs); its general form
     // keeps the tile layout (three transposes beside the int64 plaintext spill).
     constexpr bool QUADS   = LOGN <= 12 && (MODE != kModeAsym || !GENERAL);
     constexpr int QSTRIDE  = enc_quad_stride<MODE>();
@@ -766,11 +741,7 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     const uint32_t bias = compact ? two_q : 0u;
     uint32_t x[16];
 #pragma unroll
-#ifdef SEAMD_NTT_FUSE_NT
-    for (int e = 0; e < 16; e++) x[e] = __builtin_nontemporal_load(src + (e << CTOP) + t) + bias;
-#else
     for (int e = 0; e < 16; e++) x[e] = src[(e << CTOP) + t] + bias;
-#endif
     // issue the epilogue operands now; they land while the NTT runs.  At n = 16384 only `a` (HBM) is
     // prefetched; the L2-resident s_hat pairs are fetched after the NTT to stay within 96 VGPRs.
     // All epilogue accesses are in quad layout (transform.cuh, tile_to_quads): 1 KiB contiguous per wave
@@ -779,11 +750,7 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     uint32_t a[16], w[16], wp[16];
     if constexpr (MODE == kModeSym)
     {
-#ifdef SEAMD_NTT_FUSE_NT
-        load_quads_nt(a, A.c1 + (b * np + j) * N, t);
-#else
         load_quads(a, A.c1 + (b * np + j) * N, t);
-#endif
         if constexpr (!LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
     }
     ntt_tiles<LOGN>(x, T.ntt_rw + 2 * xform_table_len(N) * j, q, lds32, t);
@@ -803,11 +770,7 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
             uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
             out[e]      = csub(x[e] + q - pr, q);
         }
-#ifdef SEAMD_NTT_FUSE_NT
-        store_quads_nt(poly, out, t);
-#else
         store_quads(poly, out, t);
-#endif
     }
     else
     {

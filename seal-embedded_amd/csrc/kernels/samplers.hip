@@ -560,6 +560,13 @@ __device__ __forceinline__ void wave_redraws(uint32_t q, uint32_t crh, uint32_t 
 //                 the rejected coefficients, leaves the next prime's start counter
 // Same values, same counters as k_sample_uniform (tests: every shape against the oracle and the other forms).
 // ------------------------------------------------------------------------------------------
+// Write amplification (measured, round 4): a squeeze step yields 136 bytes of a row, so a row's 128-byte lines are
+// completed by two consecutive steps ~10 us apart and reach HBM in two pieces -- 18.3 GB written per C4 step for
+// 12.9 GB of a (1.42x).  Whole-line stores (a 16-word register carry per lane, the 16 stores of a line issued in
+// one step) bring that to 1.21x but slow the chain by 7 % (16 scattered stores back to back stall a lone wave; the
+// phases fully unrolled: 14 %, instruction cache), non-temporal accesses in the kernel streaming beside it change
+// nothing: profiles/r04_ab_bulk_pair_lines.log.  The chain is the critical path of C4, the traffic costs no time:
+// the direct stores stay.
 template <int LOGN>
 __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
 {
