@@ -168,6 +168,20 @@ __device__ __forceinline__ int thread_index()
         return threadIdx.x;
 }
 
+// C round() (half away from zero; ckks_common.c:183,192) as trunc(x + copysign(0.5 - 2^-54, x)): 3 operations
+// (v_bfi, v_add_f64, v_trunc_f64) instead of the 6-7 of the library form (trunc, subtract, compare, select,
+// copysign, add).  Exact for every double: with c = pred(0.5), a fraction below 0.5 can never be carried to the
+// next integer (x + c stays below it by more than half an ulp), a fraction of 0.5 or more always is (x + c is
+// within 2^-54 of the next integer, less than half a spacing -- and for x = 0.5 the tie 1 - 2^-54 rounds to even =
+// 1.0); |x| >= 2^52 is an integer already and absorbs c; NaN / infinity pass through.  Checked exhaustively
+// through the parity suite (every record of C2 / C3 / C4 / C5 against the oracle's round()) and on the host for
+// the boundary cases (tests/test_oracle.py::test_round_half_away_form).
+__device__ __forceinline__ double round_half_away(double x)
+{
+    const double c = 0.49999999999999994;   // 0.5 - 2^-54
+    return trunc(__dadd_rn(x, dev_copysign(c, x)));
+}
+
 // Workgroup-wide outcome of the encoder (one OR-reduction over the workgroup, returned in `wg`):
 constexpr int kWgOverflow  = 1;   // a coefficient fails the reference's overflow test (ckks_common.c:195)
 constexpr int kWgNotSmall  = 2;   // some |m| >= 2 q_min - 64 (or a non-finite value in the fast form)
@@ -273,7 +287,7 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
 #pragma unroll
     for (int e = 0; e < 16; e++)
     {
-        re[e] = round(__dmul_rn(re[e], P.n_inv));
+        re[e] = round_half_away(__dmul_rn(re[e], P.n_inv));
         amax  = fmax(amax, fabs(re[e]));
     }
     // fmax() skips NaNs: a NaN coefficient is not an overflow for the reference (ckks_common.c:195)
@@ -446,34 +460,29 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
             to_quads(uh);
             {
-                // c1 = pk1 . u_hat + NTT(e1)   (:251)
+                // c1 = pk1 . u_hat + NTT(e1)   (:251): the lazy transform outputs go through the transpose as they
+                // are; one canonicalisation at the end (modarith.cuh, add_mul_canon)
                 uint32_t w[16], wp[16];
-#pragma unroll
-                for (int e = 0; e < 16; e++) y[e] = canon4(y[e], q, two_q);
                 to_quads(y);
                 ld_pairs<QUADS>(w, wp, T.pk1 + kb, tg);
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                {
-                    uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
-                    y[e]        = csub(pr + y[e], q);
-                }
+                for (int e = 0; e < 16; e++) y[e] = add_mul_canon(y[e], uh[e], w[e], wp[e], q, two_q);
                 st_poly<QUADS>(A.c1 + pb, y, tg);
             }
-#pragma unroll
-            for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             to_quads(x);
-            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, tg);
+            if (A.ntt_pte)
+            {
+                uint32_t cx[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) cx[e] = canon4(x[e], q, two_q);
+                st_poly<QUADS>(A.ntt_pte + pb, cx, tg);
+            }
             {
                 // c0 = pk0 . u_hat + NTT(m + e0)   (:255)
                 uint32_t w[16], wp[16], out[16];
                 ld_pairs<QUADS>(w, wp, T.pk0 + kb, tg);
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                {
-                    uint32_t pr = csub(mul_shoup_lazy(uh[e], w[e], wp[e], q), q);
-                    out[e]      = csub(pr + x[e], q);
-                }
+                for (int e = 0; e < 16; e++) out[e] = add_mul_canon(x[e], uh[e], w[e], wp[e], q, two_q);
                 st_poly<QUADS>(A.c0 + pb, out, tg);
             }
             if constexpr (QALIAS) __syncthreads();
@@ -551,10 +560,19 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
                 ntt_tiles<LOGN, 64 * QSTRIDE>(x, RW, q, lds32, t, qlds);
             else
                 ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            if constexpr (MODE != kModeSym)
+            {
 #pragma unroll
-            for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
-            to_quads(x);
-            if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, tg);
+                for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+            }
+            to_quads(x);   // symmetric: the lazy values in [0,4q); sub_mul_canon canonicalises once at the end
+            if (A.ntt_pte)
+            {
+                uint32_t cx[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) cx[e] = canon4(x[e], q, two_q);
+                st_poly<QUADS>(A.ntt_pte + pb, cx, tg);
+            }
             if constexpr (MODE == kModeSym)
             {
                 // c0 = -(s_hat . a) + NTT(m+e)   (ckks_sym.c:273-300); a was written to c1
@@ -570,11 +588,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
                 ld_poly<QUADS>(a, A.c1 + pb, tg);
                 ld_pairs<QUADS>(w, wp, T.s_hat + kb, tg);
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                {
-                    uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
-                    out[e]      = csub(x[e] + q - pr, q);
-                }
+                for (int e = 0; e < 16; e++) out[e] = sub_mul_canon(x[e], a[e], w[e], wp[e], q, two_q);
                 st_poly<QUADS>(A.c0 + pb, out, tg);
             }
             else
@@ -755,20 +769,35 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     }
     ntt_tiles<LOGN>(x, T.ntt_rw + 2 * xform_table_len(N) * j, q, lds32, t);
     if constexpr (MODE == kModeSym && LATE_KEY) load_quads_pairs(w, wp, T.s_hat + (size_t)2 * N * j, t);
+    // n <= 4096: the symmetric epilogue takes the LAZY transform output and canonicalises once (modarith.cuh,
+    // sub_mul_canon); at n >= 8192 that form costs registers the kernel does not have (96-VGPR cap at n = 16384:
+    // 36 B of spills) and the separate canonicalisation stays
+    constexpr bool LAZY_EPI = MODE == kModeSym && LOGN <= 12;
+    if constexpr (!LAZY_EPI)
+    {
 #pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+        for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
+    }
     // one prime per launch: the exchange plane is free after the NTT's last barrier, the wave-local
     // transpose runs inside it (unpadded rows: the plane has no room for more at n = 16384 beside the chains)
     tile_to_quads<16>(x, lds32, t);
-    if (A.ntt_pte) store_quads(A.ntt_pte + (b * np + j) * N, x, t);
+    if (A.ntt_pte)
+    {
+        uint32_t cx[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) cx[e] = LAZY_EPI ? canon4(x[e], q, two_q) : x[e];
+        store_quads(A.ntt_pte + (b * np + j) * N, cx, t);
+    }
     if constexpr (MODE == kModeSym)
     {
         uint32_t out[16];
 #pragma unroll
         for (int e = 0; e < 16; e++)
         {
-            uint32_t pr = csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q);
-            out[e]      = csub(x[e] + q - pr, q);
+            if constexpr (LAZY_EPI)
+                out[e] = sub_mul_canon(x[e], a[e], w[e], wp[e], q, two_q);
+            else
+                out[e] = csub(x[e] + q - csub(mul_shoup_lazy(a[e], w[e], wp[e], q), q), q);
         }
         store_quads(poly, out, t);
     }

@@ -129,4 +129,23 @@ __device__ __forceinline__ uint32_t canon4(uint32_t x, uint32_t q, uint32_t two_
     return csub(min(x, x - two_q), q);
 }
 
+// Fused epilogues on a LAZY transform output x in [0,4q) (round 4: 11 / 10 operations per coefficient instead of
+// 13-14 / 12 -- the canonicalisation of x, of the product and of the result collapse into one canon4):
+//   x - y*w mod q:  u = x mod 2q in [0,2q);  p = y*w - h*q in [0,2q);  u + 2q - p in (0,4q)  -> canon4
+//   x + y*w mod q:  u + p in [0,4q)                                                          -> canon4
+// Same residues as  csub(canon4(x) + q - csub(p)),  csub(csub(p) + canon4(x))  (poly_*_mod_inpl,
+// polymodarith.h:39-101): everything is exact arithmetic mod q below 2^32 (4q < 2^32).
+__device__ __forceinline__ uint32_t sub_mul_canon(uint32_t x, uint32_t y, uint32_t w, uint32_t wp, uint32_t q,
+                                                  uint32_t two_q)
+{
+    const uint32_t u = min(x, x - two_q);
+    return canon4(u + two_q - mul_shoup_lazy(y, w, wp, q), q, two_q);
+}
+__device__ __forceinline__ uint32_t add_mul_canon(uint32_t x, uint32_t y, uint32_t w, uint32_t wp, uint32_t q,
+                                                  uint32_t two_q)
+{
+    const uint32_t u = min(x, x - two_q);
+    return canon4(u + mul_shoup_lazy(y, w, wp, q), q, two_q);
+}
+
 }  // namespace seamd

@@ -378,3 +378,39 @@ def test_oracle_is_sanitizer_clean():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "all shapes clean under ASan + UBSan" in r.stdout
+
+
+def test_round_half_away_form():
+    """The device encoder rounds with trunc(x + copysign(0.5 - 2^-54, x)) (encode_encrypt.hip, round_half_away: 3
+    VALU operations instead of the library's 6-7).  It must equal C round() -- what ckks_common.c:183,192 calls --
+    for EVERY double: checked here against libm's round() on the boundary cases (k + 0.5 and its neighbours over
+    30 binades, pred(0.5), the 2^52 / 2^53 integers, zeros, extremes) and on 2 M random doubles of all magnitudes.
+    (NaN / infinity never reach it: the fast kernels decline such plaintexts; both forms pass them through.)"""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.round.restype = ctypes.c_double
+    libm.round.argtypes = [ctypes.c_double]
+    c = np.float64(0.49999999999999994)
+    assert c == np.nextafter(np.float64(0.5), np.float64(0.0))
+    form = lambda x: np.trunc(x + np.copysign(c, x))
+    xs = [0.0, -0.0, 0.5, -0.5, float(c), -float(c), 1.5, 2.5, -2.5, 4503599627370495.5, 4503599627370496.0,
+          4503599627370497.0, 9007199254740992.0, 9007199254740993.0, 1e300, -1e300, 5e-324, 2.2250738585072014e-308]
+    for k in range(-40, 41):
+        for e in range(0, 52, 3):
+            base = float(k) * 2.0 ** e + 0.5
+            for v in (base, np.nextafter(base, np.inf), np.nextafter(base, -np.inf)):
+                xs.append(float(v))
+    rng = np.random.default_rng(7)
+    mant = rng.random(2_000_000) * 2 - 1
+    expo = rng.integers(-60, 64, 2_000_000)
+    xs = np.concatenate([np.array(xs, dtype=np.float64), mant * np.exp2(expo.astype(np.float64)),
+                         np.trunc(mant * 1e6) + 0.5, np.nextafter(np.trunc(mant * 1e9) + 0.5, 0.0)])
+    want = np.array([libm.round(float(v)) for v in xs[:4000]], dtype=np.float64)
+    assert (form(xs[:4000]) == want).all()
+    # the rest vectorised: C round() == sign(x) * floor(|x| + 0.5) computed EXACTLY (split off the integer part first)
+    ax = np.abs(xs)
+    ip = np.floor(ax)
+    ref = np.copysign(ip + (ax - ip >= 0.5), xs)          # ax - ip is exact for doubles
+    got = form(xs)
+    assert (got == ref).all() and (np.signbit(got) == np.signbit(ref)).all()

@@ -90,6 +90,27 @@ DEFKSEQ(k_mix_keccak, "v_xor_b32 %0, %0, %1\n\tv_bitop3_b32 %0, %0, %1, %2 bitop
 DEFKSEQ(k_mix_xor_align, "v_xor_b32 %0, %0, %1\n\tv_alignbit_b32 %0, %0, %1, 7", 2)
 DEFKSEQ(k_mix_ntt, "v_sub_u32 %0, %0, %1\n\tv_min_u32 %0, %0, %1\n\tv_mul_hi_u32 %0, %0, %2\n\tv_mul_lo_u32 %0, %0, %1\n\tv_add3_u32 %0, %0, %1, %2", 5)
 
+// The same three opcodes in RUNS: 8 (or 4 + 4) instructions of one kind back to back, then the next kind -- does the
+// fast class need homogeneous neighbours in the instruction stream of ONE wave?
+#define DEFKRUNS(NAME, A1, A2, A3)                                                         \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed)             \
+    {                                                                                      \
+        uint32_t x[8], y = seed ^ threadIdx.x, z = seed * 3 + blockIdx.x;                  \
+        for (int c = 0; c < 8; c++) x[c] = threadIdx.x * 977 + c + seed;                   \
+        for (int i = 0; i < ITER / 3; i++)                                                 \
+        {                                                                                  \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) asm volatile(A1 : "+v"(x[c]) : "v"(y), "v"(z)); \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) asm volatile(A2 : "+v"(x[c]) : "v"(y), "v"(z)); \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) asm volatile(A3 : "+v"(x[c]) : "v"(y), "v"(z)); \
+        }                                                                                  \
+        uint32_t acc = 0;                                                                  \
+        for (int c = 0; c < 8; c++) acc ^= x[c];                                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                  \
+    }
+DEFKRUNS(k_runs8_keccak, "v_xor_b32 %0, %0, %1", "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xd2", "v_alignbit_b32 %0, %0, %1, 7")
+DEFKRUNS(k_runs8_xxa, "v_xor_b32 %0, %0, %1", "v_xor_b32 %0, %0, %2", "v_alignbit_b32 %0, %0, %1, 7")
+DEFKRUNS(k_runs8_xxx, "v_xor_b32 %0, %0, %1", "v_xor_b32 %0, %0, %2", "v_xor_b32 %0, %0, %1")
+
 // 64-bit ops on register pairs
 #define DEFK64(NAME, ASM)                                                                  \
     __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed)             \
@@ -157,7 +178,7 @@ int main()
     R(k_lshl64) R(k_fma64) R(k_mul64) R(k_add64) R(k_lshladd64)
     R(k_and) R(k_or) R(k_not) R(k_mov) R(k_subrev) R(k_lshr) R(k_ashr) R(k_max) R(k_or3) R(k_bfe) R(k_add_co) R(k_addc_co)
     R(k_add_f32) R(k_mul_f32) R(k_xor_e64) R(k_add_e64) R(k_xor_sdwa) R(k_accw)
-    R(k_mix_keccak) R(k_mix_xor_align) R(k_mix_ntt)
+    R(k_mix_keccak) R(k_mix_xor_align) R(k_mix_ntt) R(k_runs8_keccak) R(k_runs8_xxa) R(k_runs8_xxx)
     R(k_max64) R(k_rndne64) R(k_mad6432) R(k_cvt_i32_f64) R(k_cvt_f64_i32) R(k_cmp_gt) R(k_cmp_cnd)
     hipFree(d);
     return 0;
