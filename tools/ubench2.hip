@@ -111,6 +111,69 @@ DEFKRUNS(k_runs8_keccak, "v_xor_b32 %0, %0, %1", "v_bitop3_b32 %0, %0, %1, %2 bi
 DEFKRUNS(k_runs8_xxa, "v_xor_b32 %0, %0, %1", "v_xor_b32 %0, %0, %2", "v_alignbit_b32 %0, %0, %1, 7")
 DEFKRUNS(k_runs8_xxx, "v_xor_b32 %0, %0, %1", "v_xor_b32 %0, %0, %2", "v_xor_b32 %0, %0, %1")
 
+// Which of the two is it -- homogeneous neighbours, or INDEPENDENT neighbours?  k_mixind: the three opcodes
+// alternate instruction by instruction, but adjacent instructions work on different chains (independent);
+// k_runsN: runs of N independent instructions of one kind; k_dep1: ONE dependent chain per lane.
+#define OPSEL(K) ((K) % 3 == 0 ? "v_xor_b32 %0, %0, %1" : (K) % 3 == 1 ? "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xd2" : "v_alignbit_b32 %0, %0, %1, 7")
+__global__ __launch_bounds__(256) void k_mixind(uint32_t* out, uint32_t seed)
+{
+    uint32_t x[8], y = seed ^ threadIdx.x, z = seed * 3 + blockIdx.x;
+    for (int c = 0; c < 8; c++) x[c] = threadIdx.x * 977 + c + seed;
+    for (int i = 0; i < ITER / 3; i++)
+    {
+#define ONE(C, K) if ((K) % 3 == 0) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[C]) : "v"(y), "v"(z)); \
+                  else if ((K) % 3 == 1) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xd2" : "+v"(x[C]) : "v"(y), "v"(z)); \
+                  else asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x[C]) : "v"(y), "v"(z));
+        _Pragma("unroll") for (int r = 0; r < 3; r++)
+        {
+            ONE(0, 0 + r) ONE(1, 1 + r) ONE(2, 2 + r) ONE(3, 0 + r) ONE(4, 1 + r) ONE(5, 2 + r) ONE(6, 0 + r) ONE(7, 1 + r)
+        }
+#undef ONE
+    }
+    uint32_t acc = 0;
+    for (int c = 0; c < 8; c++) acc ^= x[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+#define DEFKRUNSN(NAME, N)                                                                 \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed)             \
+    {                                                                                      \
+        uint32_t x[8], y = seed ^ threadIdx.x, z = seed * 3 + blockIdx.x;                  \
+        for (int c = 0; c < 8; c++) x[c] = threadIdx.x * 977 + c + seed;                   \
+        for (int i = 0; i < ITER / 3; i++)                                                 \
+        {                                                                                  \
+            _Pragma("unroll") for (int g = 0; g < 8 / N; g++)                              \
+            {                                                                              \
+                _Pragma("unroll") for (int c = 0; c < N; c++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[g * N + c]) : "v"(y), "v"(z)); \
+                _Pragma("unroll") for (int c = 0; c < N; c++) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xd2" : "+v"(x[g * N + c]) : "v"(y), "v"(z)); \
+                _Pragma("unroll") for (int c = 0; c < N; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x[g * N + c]) : "v"(y), "v"(z)); \
+            }                                                                              \
+        }                                                                                  \
+        uint32_t acc = 0;                                                                  \
+        for (int c = 0; c < 8; c++) acc ^= x[c];                                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                  \
+    }
+DEFKRUNSN(k_runs1, 1)
+DEFKRUNSN(k_runs2, 2)
+DEFKRUNSN(k_runs4, 4)
+__global__ __launch_bounds__(256) void k_dep1_xor(uint32_t* out, uint32_t seed)
+{
+    uint32_t x = seed ^ threadIdx.x, y = seed * 3 + blockIdx.x;
+    for (int i = 0; i < ITER; i++)
+    {
+        _Pragma("unroll") for (int c = 0; c < 8; c++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+__global__ __launch_bounds__(256) void k_dep1_alignbit(uint32_t* out, uint32_t seed)
+{
+    uint32_t x = seed ^ threadIdx.x, y = seed * 3 + blockIdx.x;
+    for (int i = 0; i < ITER; i++)
+    {
+        _Pragma("unroll") for (int c = 0; c < 8; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+
 // 64-bit ops on register pairs
 #define DEFK64(NAME, ASM)                                                                  \
     __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed)             \
@@ -179,6 +242,7 @@ int main()
     R(k_and) R(k_or) R(k_not) R(k_mov) R(k_subrev) R(k_lshr) R(k_ashr) R(k_max) R(k_or3) R(k_bfe) R(k_add_co) R(k_addc_co)
     R(k_add_f32) R(k_mul_f32) R(k_xor_e64) R(k_add_e64) R(k_xor_sdwa) R(k_accw)
     R(k_mix_keccak) R(k_mix_xor_align) R(k_mix_ntt) R(k_runs8_keccak) R(k_runs8_xxa) R(k_runs8_xxx)
+    R(k_mixind) R(k_runs1) R(k_runs2) R(k_runs4) R(k_dep1_xor) R(k_dep1_alignbit)
     R(k_max64) R(k_rndne64) R(k_mad6432) R(k_cvt_i32_f64) R(k_cvt_f64_i32) R(k_cmp_gt) R(k_cmp_cnd)
     hipFree(d);
     return 0;
