@@ -330,12 +330,10 @@ def load_valu_mix(src_hash):
         return {}
 
 
-def kernel_cpi(vm, kernel, mode, logn, mixed=False):
+def kernel_cpi(vm, kernel, mode, logn):
     ks = vm.get("kernels", {})
     for key in (f"{kernel}@{mode}{logn}", f"{kernel}@{logn}", kernel):
         if key in ks:
-            if mixed:
-                return ks[key].get("mixed_stream", {}).get("cycles_per_inst", ks[key]["cycles_per_inst"])
             return ks[key]["cycles_per_inst"]
     return None
 
@@ -763,35 +761,28 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         # v_sub issue in ~2.4 cycles, v_bitop3 in ~3.5, the rest in 4: tools/ubench2, tools/valu_mix.py)
         vm, weighted = load_valu_mix(src_hash), None
         if vm:
-            logn, cyc, cycm, cpis, covered = n.bit_length() - 1, 0.0, 0.0, {}, 0
+            logn, cyc, cpis, covered = n.bit_length() - 1, 0.0, {}, 0
             for s in used:
                 for k in STAGE_KERNELS.get(s, (KERNEL_NAMES[s],)):
                     if k not in sq:
                         continue
                     cpi = kernel_cpi(vm, k, mode, logn)
-                    cpm = kernel_cpi(vm, k, mode, logn, mixed=True)
                     ki = sq[k]["valu_wave_insts_per_step"]
                     cyc += ki * (cpi if cpi is not None else 4.0)
-                    cycm += ki * (cpm if cpm is not None else 4.0)
                     covered += ki if cpi is not None else 0
                     if cpi is not None:
                         cpis[k] = cpi
             wf = cyc / simds / VALU_CLOCK_HZ * 1e3
-            wm = cycm / simds / VALU_CLOCK_HZ * 1e3
             weighted = {"floor_ms": wf, "frac": wf / ms_per_step,
                         "floor_ms_at_sampled_clock": wf * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) if clock else None,
                         "frac_at_sampled_clock": (wf * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) / ms_per_step
                                                   if clock else None),
                         "cycles_per_inst": cpis, "insts_covered": covered / insts if insts else None,
-                        # single-opcode rates do not compose: the same bound scaled by what tools/ubench2's MIXED
-                        # streams of the matching opcode mix reach (Keccak mix 1.13x, butterfly mix 1.055x)
-                        "mixed_stream": {"floor_ms": wm, "frac": wm / ms_per_step,
-                                         "frac_at_sampled_clock": (wm * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6)
-                                                                   / ms_per_step if clock else None)},
                         "source": "profiles/valu_mix.json: static opcode mix of each kernel's hot loops (hipcc -S) x "
-                                  "per-opcode issue cycles measured by tools/ubench2 on this GPU model; single-opcode "
-                                  "streams reach these rates, a mixed Keccak stream measures ~10 % above this bound "
-                                  "(DESIGN.md section 5)"}
+                                  "per-opcode issue cycles measured by tools/ubench2 on this GPU model.  A stream whose "
+                                  "neighbouring instructions are independent reaches this bound whatever its mix "
+                                  "(ubench2 k_mixind / k_runs*); a dependent instruction right behind its producer "
+                                  "costs ~1.2 cycles more (k_mix_keccak) -- DESIGN.md section 5"}
         valu = {"bound": "valu", "wave_insts_per_step": insts, "simds": simds, "clock_hz": VALU_CLOCK_HZ,
                 "floor_ms": floor_ms, "frac": floor_ms / ms_per_step,
                 # the same floor at the clock the chip actually sustained under this workload (sampled above)
