@@ -102,9 +102,23 @@ def test_bench_contract_constants():
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"',
                 '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"',
                 '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"',
-                '"cores"', '"kind"', '"sample"', '"other_configs"', '"valu"'):
+                '"cores"', '"kind"', '"sample"', '"other_configs"', '"valu"', '"floor_ms_weighted"', '"frac_weighted"',
+                '"gather_verified"', '"per_source_GB/s"', '"per_thread_value"'):
         assert key in src, key
     assert len(bench.kernel_source_hash()) == 16
+    # optional workloads beyond BASELINE.json carry the same per-unit byte formulas
+    assert wl["x1"][:3] == (16384, 6, "asym") and wl["x2"][:3] == (8192, 6, "sym")
+    # the opcode-weighted VALU bound: profiles/valu_mix.json is stamped with the kernel sources it was built from and
+    # covers every kernel of the BASELINE workloads
+    vm = bench.load_valu_mix(bench.kernel_source_hash())
+    if not vm:      # stale evidence is not a correctness failure: bench.py prints null for these fields then
+        pytest.skip("profiles/valu_mix.json was built for other kernel sources: python tools/valu_mix.py profiles/r04_ubench2.txt")
+    for kern, mode, logn in (("k_sample_uniform", "sym", 12), ("k_sample_cbd", "sym", 12), ("k_encode_encrypt", "sym", 12),
+                             ("k_encode_encrypt", "asym", 12), ("k_encode_encrypt", "encode", 12),
+                             ("k_bulk_pair", "sym", 14), ("k_candidates", "sym", 14), ("k_ntt_fuse", "sym", 14),
+                             ("k_encode_rns", "sym", 14), ("k_sample_ternary", "asym", 12)):
+        cpi = bench.kernel_cpi(vm, kern, mode, logn)
+        assert cpi is not None and 2.2 < cpi <= 4.2, (kern, cpi)
 
 
 def _run_bench(world, extra, tmp_path):
