@@ -659,6 +659,8 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
                                ("seed-compressed", world * B * rec_bytes + B * rec_bytes)):
                 if plan == "seed-compressed" and mode != "sym":
                     continue
+                if plan == "full" and os.environ.get("SE_BENCH_TEST_NO_FULL_GATHER"):
+                    continue                          # test hook: pretend the root cannot hold both slabs
                 if be.free_bytes() < need + margin:
                     continue
                 try:

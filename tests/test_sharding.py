@@ -186,6 +186,20 @@ def test_bench_three_ranks_seed_and_encode_forms(tmp_path):
     assert d["n_gpus"] == 3 and d["gather"]["gather_verified"] is True and d["gather"]["verified_records"] == 6
 
 
+def test_bench_seed_compressed_gather_is_verified_too(tmp_path):
+    """When the root cannot hold both gathered slabs (test hook) a symmetric run gathers c0 + the 64-byte shareable
+    seeds; the untimed verification compares both with what the root re-encrypts itself."""
+    os.environ["SE_BENCH_TEST_NO_FULL_GATHER"] = "1"
+    try:
+        d = _run_bench(2, ["--steps", "1", "--warmup", "1", "--workload", "c1", "--batch", "3", "--others", "none",
+                           "--no-cpu-baseline"], tmp_path)
+    finally:
+        os.environ.pop("SE_BENCH_TEST_NO_FULL_GATHER", None)
+    g = d["gather"]
+    assert g["form"] == "seed-compressed" and g["gather_verified"] is True and g["verified_records"] == 6
+    assert g["bytes_into_root"] == 3 * 4 * 1024 + 3 * 64
+
+
 def test_launcher_with_more_ranks_than_devices(tmp_path):
     """torch.distributed.run started 2 ranks on a box that shows ONE device: rank 1 idles through the same
     collective sequence (class Collectives), rank 0 measures, the line says what happened -- and still has its
