@@ -501,6 +501,29 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             }
             ntt_tiles<LOGN>(uh, RW, q, lds32, t);
             to_quads(uh);
+            // n = 16384 (1 024 threads: 128 VGPRs): u_hat waits in LDS while the other two transforms run -- the
+            // encoder's FP64 plane is twice the NTT plane, so the upper half of the allocation is free after the
+            // encode; thread-private slots ([e][t]: conflict-free, no barrier).  76 B of scratch per lane without it, 28 B with (three
+            // root-table addresses the compiler still carries across the prime loop).
+            constexpr bool PARK = LOGN == 14 && !GENERAL;
+            uint32_t *park = lds32 + G::SLOTS + t;
+            static_assert(!PARK || (size_t)G::SLOTS * sizeof(double) >= ((size_t)G::SLOTS + 16 * G::THREADS) * sizeof(uint32_t),
+                          "the parked polynomial fits behind the NTT plane inside the encoder's plane");
+            auto park_store = [&]() {
+                if constexpr (PARK)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) park[e * G::THREADS] = uh[e];
+                }
+            };
+            auto park_load = [&]() {
+                if constexpr (PARK)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) uh[e] = park[e * G::THREADS];
+                }
+            };
+            park_store();
             // c1 = pk1 . u_hat + NTT(e1)   (:251, :263-272)
             const int8_t *ep = A.err + b * 2 * N + N + tg;
 #pragma unroll
@@ -513,6 +536,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             to_quads(x);
+            park_load();
             {
                 uint32_t w[16], wp[16], out[16];
                 ld_pairs<QUADS>(w, wp, T.pk1 + kb, tg);
@@ -531,6 +555,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             for (int e = 0; e < 16; e++) x[e] = canon4(x[e], q, two_q);
             to_quads(x);
             if (A.ntt_pte) st_poly<QUADS>(A.ntt_pte + pb, x, tg);
+            park_load();
             {
                 uint32_t w[16], wp[16], out[16];
                 ld_pairs<QUADS>(w, wp, T.pk0 + kb, tg);
