@@ -21,6 +21,7 @@
 #include "../se_types.h"
 #include "kernel_args.h"
 #include "keccak.cuh"
+#include "keccak_sync.cuh"
 #include "modarith.cuh"
 
 namespace seamd {
@@ -851,26 +852,42 @@ __device__ __forceinline__ uint32_t byte_window(const uint32_t (&w)[24], int byt
     return __builtin_amdgcn_alignbit(hi, w[wi], sh);
 }
 
-__global__ __launch_bounds__(256) void k_sample_cbd(CbdArgs A)
+// Round 4: 512-thread workgroups (two waves per SIMD and workgroup) and the phase-synchronised permutation of
+// keccak_sync.cuh -- waves of one SIMD only pair their v_xor / v_bitop3 when they are in the same phase of the round
+// (profiles/r04_ubench7_keccak_schedules.txt).  -DSEAMD_CBD_NOSYNC builds the round-3 form for the A/B.
+#ifdef SEAMD_CBD_NOSYNC
+constexpr int kCbdThreads = 256;
+#else
+constexpr int kCbdThreads = 512;
+#endif
+__global__ __launch_bounds__(kCbdThreads) void k_sample_cbd(CbdArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * A.blocks_per_ct;
-    if (gid >= total) return;
+    if (gid >= total) return;   // whole waves past the end leave before the first barrier; partial waves stay
     const size_t b   = gid / A.blocks_per_ct;
     const uint32_t k = (uint32_t)(gid - b * A.blocks_per_ct);
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
     uint64_t ctr = (A.ctr_base ? A.ctr_base[b] : 0) + k;
+    uint32_t w[24];
+#ifdef SEAMD_CBD_NOSYNC
     KeccakState st;
     prng_absorb(st, seed, ctr);
     keccak_f1600_fresh<true>(st);  // only 96 of the 200 state bytes are consumed (folded theta: keccak.cuh)
-    uint32_t w[24];
 #pragma unroll
     for (int i = 0; i < 12; i++)
     {
         w[2 * i]     = st.lo[i];
         w[2 * i + 1] = st.hi[i];
     }
+#else
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = seed[i];
+    w[16] = (uint32_t)ctr;
+    w[17] = (uint32_t)(ctr >> 32);
+    keccak_fresh96_sync(w, &kKeccakRC[0][0]);
+#endif
     // sample i = popcnt(bytes 6i,6i+1, low 5 bits of 6i+2) - popcnt(bytes 6i+3,6i+4, low 5 of 6i+5)
     uint32_t packed[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1227,7 +1244,7 @@ hipError_t launch_sample_cbd(const CbdArgs &A, hipStream_t st)
 {
     size_t total = (size_t)A.B * A.blocks_per_ct;
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sample_cbd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_sample_cbd, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A);
     return hipGetLastError();
 }
 

@@ -36,32 +36,43 @@ class Ins:
         self.extra_deps = []
 
 
-def build(rounds):
-    """Data-flow graph of `rounds` consecutive rounds.  Values 0..49 are the incoming state (lane i half h = 2i+h).
-    Returns (instructions in natural phase order, outgoing state values [50], number of values)."""
+def build(rounds, zero_in=(), need_out=None):
+    """Data-flow graph of `rounds` consecutive rounds.  Values 0..49 are the incoming state (lane i half h = 2i+h);
+    slots in `zero_in` are known to be zero (a freshly absorbed PRNG message: keccak.cuh, prng_absorb) and fold
+    away; with `need_out` (slots) everything the other outgoing slots need is dropped.
+    Returns (instructions in natural phase order, outgoing state values [50] (None = not produced), number of values)."""
     ins = []
     nv = [50]
-
-    def new():
-        nv[0] += 1
-        return nv[0] - 1
-
     cur = [0]
 
     def emit(op, srcs, imm=None):
-        d = new()
-        ins.append(Ins(op, d, srcs, imm))
+        nv[0] += 1
+        ins.append(Ins(op, nv[0] - 1, srcs, imm))
         ins[-1].phase = cur[0]
-        return d
+        return nv[0] - 1
 
-    A = [[2 * i, 2 * i + 1] for i in range(25)]
+    def x2(a, b):
+        if a is None:
+            return b
+        if b is None:
+            return a
+        return emit("xor", (a, b))
+
+    def x5(vals):
+        v = [t for t in vals if t is not None]
+        assert v
+        while len(v) > 3:
+            v = [emit("bitop3", tuple(v[:3]), 0x96)] + v[3:]
+        if len(v) == 3:
+            return emit("bitop3", tuple(v), 0x96)
+        if len(v) == 2:
+            return emit("xor", tuple(v))
+        return v[0]
+
+    A = [[None if 2 * i + h in zero_in else 2 * i + h for h in (0, 1)] for i in range(25)]
     for r in range(rounds):
         cur[0] = 4 * r          # phases per round: parity (fast) | rol1 (slow) | D + theta (fast) | rho (slow) | chi + iota (fast, = next parity's run)
-        C = [[None, None] for _ in range(5)]
-        for x in range(5):
-            for h in (0, 1):
-                t = emit("bitop3", (A[x][h], A[x + 5][h], A[x + 10][h]), 0x96)
-                C[x][h] = emit("bitop3", (t, A[x + 15][h], A[x + 20][h]), 0x96)
+        C = [[x5([A[x + 5 * y][h] for y in range(5)]) for h in (0, 1)] for x in range(5)]
         cur[0] = 4 * r + 1
         R1 = [[emit("alignbit", (C[x][0], C[x][1]), 31), emit("alignbit", (C[x][1], C[x][0]), 31)] for x in range(5)]
         cur[0] = 4 * r + 2
@@ -69,7 +80,7 @@ def build(rounds):
         B = [None] * 25
         for i in range(25):
             cur[0] = 4 * r + 2
-            T = [emit("xor", (A[i][h], D[i % 5][h])) for h in (0, 1)]
+            T = [x2(A[i][h], D[i % 5][h]) for h in (0, 1)]
             cur[0] = 4 * r + 3
             R = RHO[i]
             d = pi_dst(i)
@@ -90,9 +101,19 @@ def build(rounds):
         for h in (0, 1):
             An[0][h] = emit("iota", (An[0][h],), (r, h))
         A = An
+    outs = [A[i][h] for i in range(25) for h in (0, 1)]
+    if need_out is not None:
+        outs = [v if k in need_out else None for k, v in enumerate(outs)]
+        live = set(v for v in outs if v is not None)
+        kept = []
+        for i in reversed(ins):
+            if i.dst in live:
+                kept.append(i)
+                live.update(i.srcs)
+        ins = kept[::-1]
     for k, i in enumerate(ins):
         i.idx = k
-    return ins, [A[i][h] for i in range(25) for h in (0, 1)], nv[0]
+    return ins, outs, nv[0]
 
 
 def schedule(ins, outs, nvals, prio="order", gap=1, seed=0, alt=False):
@@ -108,7 +129,8 @@ def schedule(ins, outs, nvals, prio="order", gap=1, seed=0, alt=False):
     # WAR edges of the loop-carried registers: the value leaving in state slot k is written into the register the
     # incoming value k lives in, so every reader of incoming value k must come first
     for k, v in enumerate(outs):
-        producer[v].extra_deps = [u for u in users.get(k, []) if u is not producer[v]]
+        if v is not None:
+            producer[v].extra_deps = [u for u in users.get(k, []) if u is not producer[v]]
     height = {}
     for i in reversed(ins):
         h = 0
@@ -163,7 +185,7 @@ def schedule(ins, outs, nvals, prio="order", gap=1, seed=0, alt=False):
     return order
 
 
-def allocate(order, outs, nvals, ntemps, banks=None):
+def allocate(order, outs, nvals, ntemps, banks=None, zero_in=()):
     """Interval colouring onto registers 0..49 (state; incoming value k and outgoing value of slot k share register k)
     and 50..50+ntemps-1.  banks: None, or 'spread' = prefer a destination bank different from the banks of the
     value's future co-operands (register file banks = register index mod 4)."""
@@ -175,17 +197,19 @@ def allocate(order, outs, nvals, ntemps, banks=None):
         last.setdefault(i.dst, p)
         for s in i.srcs:
             last[s] = p
-    out_slot = {v: k for k, v in enumerate(outs)}
-    for v in outs:
+    out_slot = {v: k for k, v in enumerate(outs) if v is not None}
+    for v in out_slot:
         last[v] = END
     nregs = 50 + ntemps
     occ = [[] for _ in range(nregs)]     # per register: list of (start, end) = (def, last use)
     reg = {}
     for k in range(50):
+        if k in zero_in:
+            continue                      # no incoming value: the register is free from the start
         reg[k] = k
         occ[k].append((-1, last[k]))
     for v, k in out_slot.items():
-        assert defpos[v] >= last[k], "loop-carried register still live"
+        assert k in zero_in or defpos[v] >= last[k], "loop-carried register still live"
         reg[v] = k
         occ[k].append((defpos[v], END))
     consumers = {}
@@ -368,8 +392,108 @@ __global__ __launch_bounds__({threads}) void k_{name}(uint32_t* out, const uint3
 ''', info
 
 
+PROD_BASE = 8          # the product forms pin the state to v8..v57, temporaries follow
+PROD_TEMPS = 70
+
+
+def _segment(rounds, zero_in=(), need_out=None, bar=4):
+    ins, outs, nvals = build(rounds, zero_in, need_out)
+    order = schedule(ins, outs, nvals, "phased", 1, 0, False)
+    reg, peak = allocate(order, outs, nvals, PROD_TEMPS, None, zero_in)
+    return emit_asm(order, reg, PROD_BASE, SRC, None, bar), peak, len(order)
+
+
+def product_header():
+    """seal-embedded_amd/csrc/kernels/keccak_sync.cuh: the permutation of a freshly absorbed PRNG message (keccak.cuh,
+    prng_absorb) whose caller consumes the first 96 bytes, for kernels in which SEVERAL WAVES OF ONE WORKGROUP SHARE A
+    SIMD: whole-phase instruction order and an s_barrier at every change of issue class."""
+    present = set(range(19)) | {33}                  # seed (lanes 0..7), counter (lane 8), 0x1F (lane 9 lo), lane 16 hi
+    zero_in = set(range(50)) - present
+    seg0, p0, n0 = _segment(1, zero_in)
+    segm, pm, nm = _segment(2)
+    segl, pl, nl = _segment(1, (), set(range(24)))
+    peak = max(p0, pm, pl)
+    B = PROD_BASE
+    lines = [f"v_mov_b32 v{B + 18}, 0x1f", f"v_mov_b32 v{B + 33}, 0x80000000",
+             "s_load_dwordx2 s[16:17], %[rc], 0x0"] + seg0 + [
+             "s_mov_b64 s[28:29], %[rc]", "s_add_u32 s28, s28, 8", "s_addc_u32 s29, s29, 0", "s_movk_i32 s30, 11", "1:",
+             "s_load_dwordx4 s[16:19], s[28:29], 0x0", "s_add_u32 s28, s28, 16", "s_addc_u32 s29, s29, 0"] + segm + [
+             "s_sub_u32 s30, s30, 1", "s_cmp_lg_u32 s30, 0", "s_cbranch_scc1 1b",
+             "s_load_dwordx2 s[16:17], s[28:29], 0x0"] + segl
+    asm = "\\n\\t".join(lines)
+    ops = ", ".join([f'"+{{v{B + k}}}"(w[{k}])' for k in range(18)] + [f'"=&{{v{B + k}}}"(w[{k}])' for k in range(18, 24)])
+    clob = ", ".join(f'"v{B + k}"' for k in range(24, peak))
+    sclob = ", ".join(f'"s{n}"' for n in (16, 17, 18, 19, 28, 29, 30))
+    total = n0 + 11 * nm + nl
+    full_lines = ["s_mov_b64 s[28:29], %[rc]", "s_movk_i32 s30, 12", "1:",
+                  "s_load_dwordx4 s[16:19], s[28:29], 0x0", "s_add_u32 s28, s28, 16", "s_addc_u32 s29, s29, 0"] + segm + [
+                  "s_sub_u32 s30, s30, 1", "s_cmp_lg_u32 s30, 0", "s_cbranch_scc1 1b"]
+    asm_full = "\\n\\t".join(full_lines)
+    ops_full = ", ".join(f'"+{{v{B + k}}}"(s[{k}])' for k in range(50))
+    clob_full = ", ".join(f'"v{B + k}"' for k in range(50, pm))
+    null_asm = "\\n\\t".join([f"s_movk_i32 s30, {4 * 24}", "1:", "s_barrier", "s_sub_u32 s30, s30, 1", "s_cmp_lg_u32 s30, 0",
+                              "s_cbranch_scc1 1b"])
+    return f'''// keccak_sync.cuh -- GENERATED by tools/keccak_sched.py --product; do not edit.
+//
+// Keccak-f[1600] of a freshly absorbed PRNG message whose caller consumes the first 96 output bytes, as ONE inline-asm
+// block with the state pinned to v{B}..v{B + 49}, for kernels in which several waves of one workgroup share a SIMD.
+//
+// Why (tools/keccak_sched.py, profiles/r04_ubench7_keccak_schedules.txt): gfx950 issues v_xor / v_bitop3 at ~2.1 / 2.8
+// cycles per wave instruction only when TWO WAVES of a SIMD present such an instruction at the same time; next to a
+// v_alignbit (4.3 cycles, the other third of the round) of another wave they take a full slot each, and waves running
+// the same round unsynchronised settle out of phase (3.8-3.9 cycles per instruction whatever the instruction order or
+// the register assignment).  Here every round runs in whole phases -- parities | rol1 | theta | rho | chi -- with an
+// s_barrier at every change of issue class, so the waves of the workgroup that share a SIMD stay in phase: 2.96-3.2
+// cycles per instruction, 11.5-11.8 G permutations/s chip-wide against 8.9-9.9 for the compiler's code.
+// Same Boolean function as keccak.cuh (keccakf1600.c:51-316 of the reference); round 0 folds the known-zero lanes of
+// the absorbed message, the last round only produces lanes 0..11.  {total} VALU instructions per permutation.
+//
+// CONTRACT: every wave of the workgroup that has not ended executes this block the same number of times (it contains
+// {4 * 24} workgroup barriers); launch the kernel with at least 2 waves per SIMD and workgroup (>= 512 threads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace seamd {{
+
+// in: w[0..15] = seed words, w[16], w[17] = counter (lo, hi); out: w[0..23] = the first 96 bytes of the block
+__device__ __forceinline__ void keccak_fresh96_sync(uint32_t (&w)[24], const uint32_t *rc)
+{{
+    asm volatile("{asm}"
+                 : {ops}
+                 : [rc] "s"(rc)
+                 : {clob}, {sclob}, "scc");
+}}
+
+// The full permutation, state in and out (lane i = s[2 i] (lo), s[2 i + 1] (hi)): the squeeze step of a sponge whose
+// state stays in registers (12 iterations of the two-round body, {4 * 24} barriers, {12 * nm} VALU instructions).
+__device__ __forceinline__ void keccak_f1600_sync(uint32_t (&s)[50], const uint32_t *rc)
+{{
+    asm volatile("{asm_full}"
+                 : {ops_full}
+                 : [rc] "s"(rc)
+                 : {clob_full}, {sclob}, "scc");
+}}
+
+// For a wave of the workgroup that has no permutation to run while the others do: the same {4 * 24} barriers, no work.
+__device__ __forceinline__ void keccak_null_sync()
+{{
+    asm volatile("{null_asm}" : : : "s30", "scc");
+}}
+
+}}  // namespace seamd
+''', total, peak
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
+    if "--product" in sys.argv:
+        text, total, peak = product_header()
+        path = os.path.join(here, "..", "seal-embedded_amd", "csrc", "kernels", "keccak_sync.cuh")
+        with open(path, "w") as f:
+            f.write(text)
+        print(f"keccak_sync.cuh: {total} VALU instructions per permutation, registers v{PROD_BASE}..v{PROD_BASE + peak - 1}")
+        return
     parts = ['''// GENERATED by tools/keccak_sched.py -- do not edit.  Schedule / register-assignment variants of the lane-per-state
 // Keccak-f[1600] round as inline asm, checked against and timed beside the compiler's code for keccak.cuh.
 #include <hip/hip_runtime.h>
