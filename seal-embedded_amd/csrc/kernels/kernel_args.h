@@ -170,25 +170,6 @@ hipError_t launch_lower_sym_prime(const DevParams &, const DevTables &, const Lo
 hipError_t launch_lower_asym_prime(const DevParams &, const DevTables &, const LowerAsymArgs &, size_t count,
                                    hipStream_t);
 
-// Both samplers of a symmetric ciphertext in one kernel whose waves run their permutations in lockstep
-// (kernels/lockstep.hip): B a multiple of 256, n <= 4096.
-struct LockstepArgs
-{
-    const uint8_t *share_seeds;  // [B][64]: uniform a
-    const uint8_t *seeds;        // [B][64]: CBD error (counters 0 .. n/16 - 1)
-    uint32_t *out;               // [B][nprimes][n]
-    int8_t *err;                 // [B][n]
-    uint32_t *rej_list;          // [B][rej_cap] scratch
-    uint32_t rej_cap;
-    uint32_t *spec;              // [B][spec_cap] scratch: redraw candidates
-    uint32_t spec_cap;
-    uint32_t cand_cap;           // candidates per ciphertext and prime computed beside the squeeze (<= spec_cap)
-    uint32_t B;
-    uint32_t nprimes;
-    uint64_t *ctr_out;           // optional [B]
-};
-hipError_t launch_sym_lockstep(const DevParams &, const LockstepArgs &, int logn, hipStream_t);
-
 hipError_t launch_sample_cbd(const CbdArgs &, hipStream_t);
 hipError_t launch_sample_ternary(const TernaryArgs &, hipStream_t);
 hipError_t launch_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs, uint8_t *out,

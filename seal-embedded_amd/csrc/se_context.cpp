@@ -134,7 +134,6 @@ int Context::init(size_t n, size_t nprimes, int dev)
     // measured on one 256-CU MI355X and are scaled by the CU count; results are bit-identical either way)
     if (const char *e = getenv("SE_AMD_STAGED")) debug_flags |= atoi(e) ? 512u : 1024u;
     if (const char *e = getenv("SE_AMD_SPECULATION")) spec_mode = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SE_AMD_LOCKSTEP")) lockstep_mode = atoi(e);
     dp         = to_dev_params(hp);
     dp.num_cus = (uint32_t)num_cus;
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
@@ -621,31 +620,6 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
 
     const size_t chain_waves_per_cu = ((B + 63) / 64 + (size_t)num_cus - 1) / (size_t)num_cus;
     const bool split = split_mode == 1 || (split_mode == 2 && (hp.n >= 8192 || chain_waves_per_cu < 4));
-    if (!split && lockstep_mode != 0 && !(debug_flags & (2u | 8u | 16u)) && hp.n <= 4096 && B % 256 == 0 &&
-        (lockstep_mode == 1 || chain_waves_per_cu >= 4))
-    {
-        // Round 4: both samplers in ONE kernel whose waves run their permutations in lockstep (kernels/lockstep.hip):
-        // masters squeeze, the helper wave beside each computes the redraw candidates and the CBD blocks.
-        // cand_cap: mean + 2 sigma of the draws of a polynomial (what a ciphertext needs beyond it comes from the
-        // kernel's pooled loop); SE_AMD_LOCKSTEP=0 keeps the two-kernel form, results are bit-identical.
-        double need = 0.0;
-        for (uint32_t j = 0; j < np; j++)
-        {
-            const double p_rej = (double)(0u - dp.bound[j]) / 4294967296.0;
-            const double mean  = (double)n * p_rej / (1.0 - p_rej);
-            need               = std::max(need, mean + 2.0 * sqrt(mean) + 2.0);
-        }
-        const uint32_t cand_cap = std::min<uint32_t>(spec_cap, (uint32_t)need);
-        LockstepArgs la{d_share_seeds, d_seeds, d_c1, d_err, d_rej, rej_cap, d_spec, spec_cap, cand_cap,
-                        (uint32_t)B,   np,      nullptr};
-        stage_begin(1, st);
-        SEAMD_HIP(launch_sym_lockstep(dp, la, (int)hp.logn, st));
-        stage_end(st);
-        stage_begin(3, st);
-        SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
-        stage_end(st);
-        return 0;
-    }
     if (!split)
     {
         // Simple chain: [cbd on the aux stream || uniform] -> fused encode+encrypt.

@@ -97,7 +97,6 @@ struct Context
     // public-key path: chunks the batch is cut into so that the CBD sampler of chunk k+1 runs beside the
     // fused kernel of chunk k (se_context.cpp, encrypt_asym_impl); 1 = serial
     size_t asym_chunks = getenv("SE_AMD_ASYM_CHUNKS") ? (size_t)atoi(getenv("SE_AMD_ASYM_CHUNKS")) : 1;
-    int lockstep_mode = 0;  // SE_AMD_LOCKSTEP: 0 = two-kernel samplers, 1 = the lockstep kernel whenever eligible, 2 = when the batch fills the chip
     int spec_mode = -1;    // prime speculation of small symmetric calls: -1 = estimate per call, 0 never, 1 whenever planned
     bool overlap = true;   // run independent kernels on the auxiliary stream
     int split_mode = 2;    // symmetric path: 0 = fused kernel, 1 = per-prime software pipeline

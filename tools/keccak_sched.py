@@ -403,7 +403,7 @@ def _segment(rounds, zero_in=(), need_out=None, bar=4):
     return emit_asm(order, reg, PROD_BASE, SRC, None, bar), peak, len(order)
 
 
-def product_header():
+def product_header(full=False):
     """seal-embedded_amd/csrc/kernels/keccak_sync.cuh: the permutation of a freshly absorbed PRNG message (keccak.cuh,
     prng_absorb) whose caller consumes the first 96 bytes, for kernels in which SEVERAL WAVES OF ONE WORKGROUP SHARE A
     SIMD: whole-phase instruction order and an s_barrier at every change of issue class."""
@@ -433,6 +433,25 @@ def product_header():
     clob_full = ", ".join(f'"v{B + k}"' for k in range(50, pm))
     null_asm = "\\n\\t".join([f"s_movk_i32 s30, {4 * 24}", "1:", "s_barrier", "s_sub_u32 s30, s30, 1", "s_cmp_lg_u32 s30, 0",
                               "s_cbranch_scc1 1b"])
+    # --full: also the state-in / state-out permutation and the barrier-only form (the lockstep sampler experiment of
+    # round 4, profiles/r04_ab_lockstep.log; no product kernel uses them)
+    extras = f'''// The full permutation, state in and out (lane i = s[2 i] (lo), s[2 i + 1] (hi)): the squeeze step of a sponge whose
+// state stays in registers (12 iterations of the two-round body, {4 * 24} barriers, {12 * nm} VALU instructions).
+__device__ __forceinline__ void keccak_f1600_sync(uint32_t (&s)[50], const uint32_t *rc)
+{{
+    asm volatile("{asm_full}"
+                 : {ops_full}
+                 : [rc] "s"(rc)
+                 : {clob_full}, {sclob}, "scc");
+}}
+
+// For a wave of the workgroup that has no permutation to run while the others do: the same {4 * 24} barriers, no work.
+__device__ __forceinline__ void keccak_null_sync()
+{{
+    asm volatile("{null_asm}" : : : "s30", "scc");
+}}
+
+''' if full else ""
     return f'''// keccak_sync.cuh -- GENERATED by tools/keccak_sched.py --product; do not edit.
 //
 // Keccak-f[1600] of a freshly absorbed PRNG message whose caller consumes the first 96 output bytes, as ONE inline-asm
@@ -465,30 +484,14 @@ __device__ __forceinline__ void keccak_fresh96_sync(uint32_t (&w)[24], const uin
                  : {clob}, {sclob}, "scc");
 }}
 
-// The full permutation, state in and out (lane i = s[2 i] (lo), s[2 i + 1] (hi)): the squeeze step of a sponge whose
-// state stays in registers (12 iterations of the two-round body, {4 * 24} barriers, {12 * nm} VALU instructions).
-__device__ __forceinline__ void keccak_f1600_sync(uint32_t (&s)[50], const uint32_t *rc)
-{{
-    asm volatile("{asm_full}"
-                 : {ops_full}
-                 : [rc] "s"(rc)
-                 : {clob_full}, {sclob}, "scc");
-}}
-
-// For a wave of the workgroup that has no permutation to run while the others do: the same {4 * 24} barriers, no work.
-__device__ __forceinline__ void keccak_null_sync()
-{{
-    asm volatile("{null_asm}" : : : "s30", "scc");
-}}
-
-}}  // namespace seamd
+{extras}}}  // namespace seamd
 ''', total, peak
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     if "--product" in sys.argv:
-        text, total, peak = product_header()
+        text, total, peak = product_header("--full" in sys.argv)
         path = os.path.join(here, "..", "seal-embedded_amd", "csrc", "kernels", "keccak_sync.cuh")
         with open(path, "w") as f:
             f.write(text)
