@@ -62,6 +62,14 @@ __device__ __forceinline__ void load_seed(uint32_t (&seed)[16], const uint8_t *s
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid residue
 
+// Workgroup size of the one-permutation-per-thread kernels (k_sample_cbd, k_candidates): 512 threads are two waves per
+// SIMD and workgroup, which the phase-synchronised permutation of keccak_sync.cuh keeps in phase.
+#ifdef SEAMD_CBD_NOSYNC
+constexpr int kCbdThreads = 256;
+#else
+constexpr int kCbdThreads = 512;
+#endif
+
 // MAXT: the largest workgroup the instantiation is launched with.  Up to 8 waves per workgroup (every
 // batch <= 4 x 64 x CUs, i.e. all BASELINE shapes) the kernel may use 256 VGPRs: 160, no spills; the
 // 1024-thread form is capped at 128 and spills 140 B per lane (uniform stage 6.28 -> 6.11 ms at C2).
@@ -643,20 +651,32 @@ __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
     if (active && part == 0) A.nrej[b] = nrej;
 }
 
-// candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4]; consecutive threads = consecutive k of one ciphertext
-__global__ __launch_bounds__(256) void k_candidates(UniformArgs A)
+// candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4]; consecutive threads = consecutive k of one ciphertext.
+// Round 4: 512-thread workgroups and the phase-synchronised permutation, as k_sample_cbd (-DSEAMD_CBD_NOSYNC: round 3).
+__global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * A.spec_cap;
-    if (gid >= total) return;
+    if (gid >= total) return;   // whole waves past the end leave before the first barrier; partial waves stay
     const size_t b   = gid / A.spec_cap;
     const uint32_t k = (uint32_t)(gid - b * A.spec_cap);
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
+    const uint64_t ctr = (A.ctr_in ? A.ctr_in[b] : 0) + 1 + k;
+#ifdef SEAMD_CBD_NOSYNC
     KeccakState st;
-    prng_absorb(st, seed, (A.ctr_in ? A.ctr_in[b] : 0) + 1 + k);
+    prng_absorb(st, seed, ctr);
     keccak_f1600_fresh<true>(st);   // only the first word is consumed
     A.spec[gid] = st.lo[0];
+#else
+    uint32_t w[18];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = seed[i];
+    w[16] = (uint32_t)ctr;
+    w[17] = (uint32_t)(ctr >> 32);
+    keccak_fresh4_sync(w, &kKeccakRC[0][0]);
+    A.spec[gid] = w[0];
+#endif
 }
 
 // The common case of the resolve step without any Keccak in the kernel (24 VGPRs instead of 130: 8 waves per
@@ -855,11 +875,6 @@ __device__ __forceinline__ uint32_t byte_window(const uint32_t (&w)[24], int byt
 // Round 4: 512-thread workgroups (two waves per SIMD and workgroup) and the phase-synchronised permutation of
 // keccak_sync.cuh -- waves of one SIMD only pair their v_xor / v_bitop3 when they are in the same phase of the round
 // (profiles/r04_ubench7_keccak_schedules.txt).  -DSEAMD_CBD_NOSYNC builds the round-3 form for the A/B.
-#ifdef SEAMD_CBD_NOSYNC
-constexpr int kCbdThreads = 256;
-#else
-constexpr int kCbdThreads = 512;
-#endif
 __global__ __launch_bounds__(kCbdThreads) void k_sample_cbd(CbdArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1211,7 +1226,7 @@ hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st)
 {
     const size_t total = (size_t)A.B * A.spec_cap;
     if (total == 0 || !A.spec) return hipSuccess;
-    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A);
     return hipGetLastError();
 }
 

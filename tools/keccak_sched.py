@@ -412,7 +412,8 @@ def product_header(full=False):
     seg0, p0, n0 = _segment(1, zero_in)
     segm, pm, nm = _segment(2)
     segl, pl, nl = _segment(1, (), set(range(24)))
-    peak = max(p0, pm, pl)
+    seg1, p1, n1 = _segment(1, (), {0})               # last round of a block whose caller consumes the first word only
+    peak = max(p0, pm, pl, p1)
     B = PROD_BASE
     lines = [f"v_mov_b32 v{B + 18}, 0x1f", f"v_mov_b32 v{B + 33}, 0x80000000",
              "s_load_dwordx2 s[16:17], %[rc], 0x0"] + seg0 + [
@@ -420,6 +421,10 @@ def product_header(full=False):
              "s_load_dwordx4 s[16:19], s[28:29], 0x0", "s_add_u32 s28, s28, 16", "s_addc_u32 s29, s29, 0"] + segm + [
              "s_sub_u32 s30, s30, 1", "s_cmp_lg_u32 s30, 0", "s_cbranch_scc1 1b",
              "s_load_dwordx2 s[16:17], s[28:29], 0x0"] + segl
+    asm4 = "\\n\\t".join(lines[:len(lines) - len(segl)] + seg1)
+    ops4 = ", ".join(f'"+{{v{B + k}}}"(w[{k}])' for k in range(18))
+    clob4 = ", ".join(f'"v{B + k}"' for k in range(18, peak))
+    total4 = n0 + 11 * nm + n1
     asm = "\\n\\t".join(lines)
     ops = ", ".join([f'"+{{v{B + k}}}"(w[{k}])' for k in range(18)] + [f'"=&{{v{B + k}}}"(w[{k}])' for k in range(18, 24)])
     clob = ", ".join(f'"v{B + k}"' for k in range(24, peak))
@@ -482,6 +487,16 @@ __device__ __forceinline__ void keccak_fresh96_sync(uint32_t (&w)[24], const uin
                  : {ops}
                  : [rc] "s"(rc)
                  : {clob}, {sclob}, "scc");
+}}
+
+// the same block for a caller that consumes its first 4 bytes (a redraw candidate, sample.c:54): in w[0..17] as above,
+// out w[0]; the last round shrinks to what that word needs ({total4} VALU instructions per permutation)
+__device__ __forceinline__ void keccak_fresh4_sync(uint32_t (&w)[18], const uint32_t *rc)
+{{
+    asm volatile("{asm4}"
+                 : {ops4}
+                 : [rc] "s"(rc)
+                 : {clob4}, {sclob}, "scc");
 }}
 
 {extras}}}  // namespace seamd

@@ -126,8 +126,19 @@ def kernel_mix(lines, frag, cyc):
     # rounds: ~3 trips)
     insts, inst_loops = [], []
     cur_loops, pending_label = (), None
+    # loops INSIDE an inline-asm block (keccak_sync.cuh: "s_movk_i32 s30, <trips>" / "1:" ... "s_cbranch_scc1 1b") carry
+    # no compiler annotation: they get a pseudo header with the trip count the block states itself
+    asm_loop, asm_trips, last_movk, n_asm = None, {}, None, 0
     for l in body:
         t = l.strip()
+        ma = re.match(r"^s_movk_i32 s30, (\w+)", t)
+        if ma:
+            last_movk = float(int(ma.group(1), 0))
+        if re.match(r"^\d+:$", t):
+            n_asm += 1
+            asm_loop = "asm%d" % n_asm
+            asm_trips[asm_loop] = last_movk if last_movk else DEFAULT_TRIP
+            continue
         m = re.match(r"^\.(LBB\w+):", t)
         if m:
             pending_label, cur_loops = m.group(1)[1:], ()
@@ -151,7 +162,9 @@ def kernel_mix(lines, frag, cyc):
             continue
         pending_label = None
         insts.append(t)
-        inst_loops.append(cur_loops)
+        inst_loops.append(cur_loops + ((asm_loop,) if asm_loop else ()))
+        if asm_loop and re.match(r"^s_cbranch_scc1 \d+b", t):
+            asm_loop = None
     is_valu = [t.split()[0].startswith("v_") for t in insts]
     size = collections.Counter()
     for v, ls in zip(is_valu, inst_loops):
@@ -169,7 +182,9 @@ def kernel_mix(lines, frag, cyc):
     keccak = {h for h in size if size[h] >= 150 and not any(size[c] >= 150 for c in children(h))}
     trip_of = {}
     for h in size:
-        if fixed is not None:
+        if h in asm_trips:
+            trip_of[h] = asm_trips[h]
+        elif fixed is not None:
             trip_of[h] = fixed
         elif h in keccak:
             trip_of[h] = 12.0
