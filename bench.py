@@ -75,7 +75,7 @@ KERNEL_NAMES = {"cbd": "k_sample_cbd", "uniform": "k_sample_uniform", "ternary":
 STAGE_KERNELS = {
     "uniform": ("k_sample_uniform", "k_sample_uniform_wave", "k_bulk_pair", "k_candidates", "k_resolve_light",
                 "k_resolve_wave"),
-    "ternary": ("k_sample_ternary", "k_sample_ternary_wave"),
+    "ternary": ("k_sample_ternary", "k_sample_ternary_wave", "k_sample_ternary_window", "k_sample_ternary_redo"),
     "encode_encrypt": ("k_encode_encrypt", "k_encode_encrypt_general"),
     "encode_rns": ("k_encode_rns", "k_encode_rns_general"),
 }

@@ -16,6 +16,9 @@
 //   * ternary: 96-byte block per 96 coefficients, 1-byte redraw blocks interleaved between blocks.
 //   * CBD: counters are static (base + k), fully parallel.
 #include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <algorithm>
 #include <type_traits>
 
 #include "../se_types.h"
@@ -1074,6 +1077,209 @@ __global__ __launch_bounds__(256) void k_sample_ternary_wave(TernaryArgs A)
     if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
 }
 
+// ------------------------------------------------------------------------------------------
+// Ternary u, WINDOW form (round 4).  A block and a redraw are prefixes of the SAME stream function -- block(c) = the
+// first 96 bytes, a redraw = the first byte of SHAKE256(seed || c) -- and the chain of a ciphertext only decides
+// WHICH counter plays which part: counter c is a block, then one counter per redraw of its rejected bytes (in byte
+// order, repeated while the redrawn byte is >= 0xFE: sample.c:226-238), then the next block.  The chain touches
+// nblocks + n/128 +- a few counters (75.3 +- 5.7 at n = 4096), so:
+//   1. every thread computes block(ctr0 + k)[0:96] for ONE counter k of a window of W counters of one ciphertext --
+//      one phase-synchronised permutation (keccak_sync.cuh), no chain: 102 permutations per ciphertext instead of
+//      ~75 sequential ones, ~20 us instead of ~1 ms;
+//   2. one lane per ciphertext walks the window with per-counter summaries from LDS (96-bit reject mask, first byte)
+//      and gives every counter its role: block j | redraw for coefficient p | consumed and rejected | unused;
+//   3. the threads write: block counters their 96 codes, then (after a fence and a barrier) redraw counters their one.
+// A ciphertext whose chain leaves the window (W = mean + 4.7 sigma: ~1e-6) is marked and redone by one lane of
+// k_sample_ternary_redo with the sequential algorithm of k_sample_ternary.  Same codes, same end counter (tests: against the oracle and the other forms, and
+// with a window so small that most ciphertexts take the fallback).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kTernWg = 512;
+
+// the sequential chain of ONE ciphertext on one lane (the fallback of the window form)
+__device__ void ternary_chain_lane(const uint32_t (&seed)[16], uint64_t &ctr, uint32_t n, int8_t *out)
+{
+    const uint32_t nblocks = (n + 95) / 96;
+    for (uint32_t blk = 0; blk < nblocks; blk++)
+    {
+        KeccakState st;
+        prng_absorb(st, seed, ctr);
+        ctr++;
+        keccak_f1600_fresh<true>(st);
+        const uint32_t base = blk * 96, stop = min(96u, n - base);
+        uint32_t w[24], pend[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 12; i++) w[2 * i] = st.lo[i], w[2 * i + 1] = st.hi[i];
+#pragma unroll
+        for (int wi = 0; wi < 24; wi++)
+        {
+            uint32_t codes = 0, rejbits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t r = (w[wi] >> (8 * k)) & 0xFFu;
+                rejbits |= ((r >= 0xFEu && (uint32_t)(4 * wi + k) < stop) ? 1u : 0u) << k;
+                codes |= mod3_u8(r) << (8 * k);
+            }
+            pend[wi >> 3] |= rejbits << (4 * (wi & 7));
+            if ((uint32_t)(4 * wi) < stop) *reinterpret_cast<uint32_t *>(out + base + 4 * wi) = codes;
+        }
+        while ((pend[0] | pend[1] | pend[2]) != 0)
+        {
+            KeccakState rs;
+            prng_absorb(rs, seed, ctr);
+            ctr++;
+            keccak_f1600_fresh<true>(rs);
+            const uint32_t r = rs.lo[0] & 0xFFu;
+            if (r < 0xFEu)
+            {
+                uint32_t pos;
+                if (pend[0]) { pos = __builtin_ctz(pend[0]); pend[0] &= pend[0] - 1; }
+                else if (pend[1]) { pos = 32 + __builtin_ctz(pend[1]); pend[1] &= pend[1] - 1; }
+                else { pos = 64 + __builtin_ctz(pend[2]); pend[2] &= pend[2] - 1; }
+                out[base + pos] = (int8_t)mod3_u8(r);
+            }
+        }
+    }
+}
+
+constexpr int8_t kTernRedo = 0x7F;   // codes[b][0] of a ciphertext whose chain left the window (real codes are 0, 1, 2)
+
+__global__ __launch_bounds__(kTernWg) void k_sample_ternary_window(TernaryArgs A, uint32_t W, uint32_t cpw)
+{
+    __shared__ uint32_t s_mask[kTernWg * 3];
+    __shared__ uint32_t s_role[kTernWg];    // block counter: j; accepted redraw: 0x80000000 | block counter << 8 | ordinal
+    __shared__ uint16_t s_sum[kTernWg + 8]; // per counter: rejected bytes (all 96 | first `last`) and "first byte accepted"
+    __shared__ uint32_t s_over[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ctl = tid / W;          // ciphertext of this workgroup
+    const uint32_t k   = tid - ctl * W;    // counter of its window
+    const size_t b0    = (size_t)blockIdx.x * cpw;
+    const bool valid   = ctl < cpw && b0 + ctl < A.B;
+    if (!__any(valid)) return;             // whole waves without work leave before the first barrier (scalar branch)
+    const size_t b     = valid ? b0 + ctl : (size_t)A.B - 1;
+    const uint32_t n = A.n, nblocks = (n + 95) / 96, last = n - (nblocks - 1) * 96;
+    int8_t *out = A.codes + b * n;
+
+    // 1. this thread's counter
+    uint32_t w[24];
+    {
+        uint32_t seed[16];
+        load_seed(seed, A.seeds, b);
+        const uint64_t c = (A.ctr_in ? A.ctr_in[b] : 0) + k;
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = seed[i];
+        w[16] = (uint32_t)c;
+        w[17] = (uint32_t)(c >> 32);
+        keccak_fresh96_sync(w, &kKeccakRC[0][0]);
+    }
+    {
+        uint32_t m[3] = {0, 0, 0};
+#pragma unroll
+        for (int wi = 0; wi < 24; wi++)
+        {
+            uint32_t rejbits = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) rejbits |= ((((w[wi] >> (8 * kk)) & 0xFFu) >= 0xFEu) ? 1u : 0u) << kk;
+            m[wi >> 3] |= rejbits << (4 * (wi & 7));
+        }
+        s_mask[3 * tid] = m[0], s_mask[3 * tid + 1] = m[1], s_mask[3 * tid + 2] = m[2];
+        // rejected bytes among all 96 / among the first `last` (what counts when this counter is the LAST block)
+        uint32_t l0 = m[0], l1 = m[1], l2 = m[2];
+        if (last < 32) l0 &= (1u << last) - 1u;
+        if (last <= 32) l1 = 0; else if (last < 64) l1 &= (1u << (last - 32)) - 1u;
+        if (last <= 64) l2 = 0; else if (last < 96) l2 &= (1u << (last - 64)) - 1u;
+        const uint32_t full = __popc(m[0]) + __popc(m[1]) + __popc(m[2]), part = __popc(l0) + __popc(l1) + __popc(l2);
+        s_sum[tid]  = (uint16_t)(full | (part << 7) | (((w[0] & 0xFFu) < 0xFEu) ? 0x4000u : 0u));
+        s_role[tid] = 0xFFFFFFFFu;
+        if (tid < 16) s_over[tid] = 0;
+    }
+    __syncthreads();
+
+    // 2. one lane per ciphertext deals the roles: the counters are visited in order, one summary each
+    if (tid < cpw && b0 + tid < A.B)
+    {
+        const uint32_t base = tid * W;
+        uint32_t j = 0, need = 0, cb = 0, ord = 0, c = 0;
+        for (; c < W && (j < nblocks || need > 0); c++)
+        {
+            const uint32_t sm = s_sum[base + c];
+            if (need == 0)
+            {
+                s_role[base + c] = j;
+                need = (j == nblocks - 1) ? ((sm >> 7) & 0x7Fu) : (sm & 0x7Fu);
+                cb = c, ord = 0, j++;
+            }
+            else if (sm & 0x4000u)
+            {
+                s_role[base + c] = 0x80000000u | (cb << 8) | ord;
+                ord++, need--;
+            }
+        }
+        const bool over = j < nblocks || need > 0;
+        s_over[tid]     = over ? 1u : 0u;
+        if (over)
+            A.codes[(b0 + tid) * n] = kTernRedo;     // k_sample_ternary_redo picks it up
+        else if (A.ctr_out)
+            A.ctr_out[b0 + tid] = (A.ctr_in ? A.ctr_in[b0 + tid] : 0) + c;
+    }
+    __syncthreads();
+
+    // 3. block counters write their codes, then redraw counters theirs
+    const uint32_t role = s_role[tid];
+    const bool skip     = !valid || s_over[ctl < 16 ? ctl : 0] != 0;
+    if (!skip && role < 0x80000000u)
+    {
+        const uint32_t stop = (role == nblocks - 1) ? last : 96u;
+        int8_t *dst         = out + role * 96;
+#pragma unroll
+        for (int q4 = 0; q4 < 6; q4++)
+        {
+            uint32_t cd[4];
+#pragma unroll
+            for (int wi = 0; wi < 4; wi++)
+            {
+                uint32_t codes = 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) codes |= mod3_u8((w[4 * q4 + wi] >> (8 * kk)) & 0xFFu) << (8 * kk);
+                cd[wi] = codes;
+            }
+            if ((uint32_t)(16 * q4) < stop)     // stop is a multiple of 16 (n = 2^k >= 1024)
+                *reinterpret_cast<uint4 *>(dst + 16 * q4) = make_uint4(cd[0], cd[1], cd[2], cd[3]);
+        }
+    }
+    // the block stores of this workgroup must be in L2 before a redraw byte lands inside one of their words: the stores
+    // are acknowledged (vmcnt 0) and the order is a WORKGROUP matter (an agent-scope fence writes the L2 back: 5x slower)
+    __builtin_amdgcn_s_waitcnt(0);
+    __threadfence_block();
+    __syncthreads();
+    if (!skip && role != 0xFFFFFFFFu && role >= 0x80000000u)
+    {
+        // the ord-th rejected byte of the block counter's 96
+        const uint32_t cbk = ctl * W + ((role >> 8) & 0x3FFu), ord = role & 0xFFu;
+        uint32_t m0 = s_mask[3 * cbk], m1 = s_mask[3 * cbk + 1], m2 = s_mask[3 * cbk + 2], pos = 0;
+        for (uint32_t i = 0; i <= ord; i++)
+        {
+            if (m0) { pos = __builtin_ctz(m0); m0 &= m0 - 1; }
+            else if (m1) { pos = 32 + __builtin_ctz(m1); m1 &= m1 - 1; }
+            else { pos = 64 + __builtin_ctz(m2); m2 &= m2 - 1; }
+        }
+        out[s_role[cbk] * 96 + pos] = (int8_t)mod3_u8(w[0] & 0xFFu);
+    }
+}
+
+// The ciphertexts k_sample_ternary_window could not finish (marker in codes[b][0]): sequentially, a lane each.  Launched
+// behind every window launch; with windows of mean + 4.7 sigma its lanes read one byte and leave.
+__global__ __launch_bounds__(64) void k_sample_ternary_redo(TernaryArgs A)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.B || A.codes[b * A.n] != kTernRedo) return;
+    uint32_t seed[16];
+    load_seed(seed, A.seeds, b);
+    uint64_t ctr = A.ctr_in ? A.ctr_in[b] : 0;
+    ternary_chain_lane(seed, ctr, A.n, A.codes + b * A.n);
+    if (A.ctr_out) A.ctr_out[b] = ctr;
+}
+
 // Raw PRNG blocks for tests: out[i] = SHAKE256(seed[i] || le64(ctr[i]))[0 : outlen], lane per block.
 __global__ __launch_bounds__(64) void k_prng_blocks(const uint8_t *seeds, const uint64_t *ctrs,
                                                     uint8_t *out, uint32_t outlen, uint32_t count)
@@ -1266,6 +1472,29 @@ hipError_t launch_sample_cbd(const CbdArgs &A, hipStream_t st)
 hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
 {
     if (A.B == 0) return hipSuccess;
+#ifndef SEAMD_TERNARY_NOWINDOW   // A/B builds: the chain forms of rounds 1-3 only
+    if (!(A.debug_flags & (32 | 64)))
+    {
+        // Window form (k_sample_ternary_window): W = blocks + mean + 4.7 sigma of the redraws (2 of 256 byte values are
+        // rejected), as many ciphertexts per 512-thread workgroup as fit, the window widened to the lanes that are left.
+        // n <= 4096: every batch size (102 permutations per ciphertext, no chain); beyond that the windows no longer
+        // fill a workgroup (n = 16384: 354 of 512 lanes, 1.7x the permutations of the chain) and the form serves the
+        // batches whose chains would leave SIMDs empty (up to one chain wave per SIMD: n = 16384, B = 16 384: 3.56 ms
+        // of 300-deep chains against ~1 ms).
+        // debug_flags 4096: a window of blocks + 2 counters, so that nearly every ciphertext takes the fallback (tests).
+        const uint32_t nblocks = (A.n + 95) / 96;
+        const double mean      = (double)A.n * (2.0 / 254.0);
+        uint32_t W = (A.debug_flags & 4096) ? nblocks + 2 : nblocks + (uint32_t)(mean + 4.7 * sqrt(mean) + 1.0);
+        if (W <= kTernWg && (A.n <= 4096 || A.B <= (size_t)256 * (A.num_cus ? A.num_cus : 256u)))
+        {
+            const uint32_t cpw = std::min<uint32_t>(kTernWg / W, 15u);
+            if (!(A.debug_flags & 4096)) W = kTernWg / cpw;
+            hipLaunchKernelGGL(k_sample_ternary_window, dim3((A.B + cpw - 1) / cpw), dim3(kTernWg), 0, st, A, W, cpw);
+            hipLaunchKernelGGL(k_sample_ternary_redo, dim3((A.B + 63) / 64), dim3(64), 0, st, A);
+            return hipGetLastError();
+        }
+    }
+#endif
     if (A.B <= uniform_wave_limit(A.num_cus) && !(A.debug_flags & 32))
     {
         // a handful of chains: one wave per ciphertext (see k_sample_uniform_wave)

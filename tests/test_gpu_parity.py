@@ -357,15 +357,20 @@ def test_sample_ternary_and_cbd_vs_oracle(env, n):
     seeds = seeds_np(B, f"tern-{n}")
     codes = torch.zeros((B, n), dtype=torch.int8, device=env["dev"])
     ctr_out = torch.zeros(B, dtype=torch.int64, device=env["dev"])
-    # a batch this small takes the wave-per-ciphertext kernel; flag 32 forces the lane-per-ciphertext one
+    # flag 32 forces the lane-per-ciphertext chain kernel (the form of rounds 1-3 for full batches)
     ctx.set_debug_flags(32)
     lane_codes = torch.zeros_like(codes)
     lane_ctr = torch.zeros_like(ctr_out)
     ctx.sample_ternary(dev_t(env, seeds), lane_codes, lane_ctr)
-    ctx.set_debug_flags(0)
-    ctx.sample_ternary(dev_t(env, seeds), codes, ctr_out)
-    torch.cuda.synchronize()
-    assert torch.equal(codes, lane_codes) and torch.equal(ctr_out, lane_ctr)
+    # 0: the window form (round 4: one permutation per counter of a window, roles dealt afterwards); 64: the
+    # wave-per-ciphertext chains; 4096: a window of blocks + 2 counters, so that nearly every chain leaves it and is
+    # redone by the sequential fallback of the window kernel
+    for flags in (64, 4096, 0):
+        ctx.set_debug_flags(flags)
+        codes.zero_(), ctr_out.zero_()
+        ctx.sample_ternary(dev_t(env, seeds), codes, ctr_out)
+        torch.cuda.synchronize()
+        assert torch.equal(codes, lane_codes) and torch.equal(ctr_out, lane_ctr), flags
     err = torch.zeros((B, 2 * n), dtype=torch.int8, device=env["dev"])
     ctx.sample_cbd(dev_t(env, seeds), err, 2 * (n // 16), ctr_base=ctr_out)
     torch.cuda.synchronize()

@@ -59,6 +59,7 @@ KERNELS = {
                  ("k_sample_uniform@14", "k_sample_uniformILi14ELi512ELb0E"),
                  ("k_sample_uniform@13", "k_sample_uniformILi13ELi512ELb0E"),
                  ("k_sample_cbd", "k_sample_cbd"), ("k_sample_ternary", "k_sample_ternaryILi512E"),
+                 ("k_sample_ternary_window", "k_sample_ternary_window"),
                  ("k_bulk_pair@14", "k_bulk_pairILi14E"), ("k_bulk_pair@13", "k_bulk_pairILi13E"),
                  ("k_candidates", "k_candidates"),
                  ("k_resolve_light@14", "k_resolve_lightILi14E"), ("k_resolve_light@13", "k_resolve_lightILi13E")],
