@@ -660,7 +660,10 @@ __global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * A.spec_cap;
-    if (gid >= total) return;   // whole waves past the end leave before the first barrier; partial waves stay
+#ifndef SEAMD_CBD_NOSYNC
+    if (!__any(gid < total)) return;   // whole waves past the end leave by a SCALAR branch, before the first barrier
+#endif
+    if (gid >= total) return;          // lanes of a partial wave: masked, the wave runs the permutation
     const size_t b   = gid / A.spec_cap;
     const uint32_t k = (uint32_t)(gid - b * A.spec_cap);
     uint32_t seed[16];
@@ -882,7 +885,10 @@ __global__ __launch_bounds__(kCbdThreads) void k_sample_cbd(CbdArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * A.blocks_per_ct;
-    if (gid >= total) return;   // whole waves past the end leave before the first barrier; partial waves stay
+#ifndef SEAMD_CBD_NOSYNC
+    if (!__any(gid < total)) return;   // whole waves past the end leave by a SCALAR branch, before the first barrier
+#endif
+    if (gid >= total) return;          // lanes of a partial wave: masked, the wave runs the permutation
     const size_t b   = gid / A.blocks_per_ct;
     const uint32_t k = (uint32_t)(gid - b * A.blocks_per_ct);
     uint32_t seed[16];
