@@ -889,6 +889,9 @@ __global__ __launch_bounds__(kCbdThreads) void k_sample_cbd(CbdArgs A)
     if (!__any(gid < total)) return;   // whole waves past the end leave by a SCALAR branch, before the first barrier
 #endif
     if (gid >= total) return;          // lanes of a partial wave: masked, the wave runs the permutation
+#ifdef SEAMD_ABL_CBD_PRIO
+    __builtin_amdgcn_s_setprio(SEAMD_ABL_CBD_PRIO);   // A/B only: CBD waves above the chain waves they share SIMDs with
+#endif
     const size_t b   = gid / A.blocks_per_ct;
     const uint32_t k = (uint32_t)(gid - b * A.blocks_per_ct);
     uint32_t seed[16];
