@@ -89,6 +89,9 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
     // dynamic LDS: reserved (> 80 KiB) to pin one workgroup per CU; its first bytes hold the
     // per-wave rank -> lane table of the balanced redraw phase
     extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];
+#ifdef SEAMD_ABL_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(SEAMD_ABL_CHAIN_PRIO);   // A/B only: chain waves above the CBD waves beside them
+#endif
     const int lane      = threadIdx.x & 63;
     const int wave      = threadIdx.x >> 6;
     uint8_t *rank2lane  = pin_lds + wave * 64;
