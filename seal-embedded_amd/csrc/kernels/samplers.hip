@@ -655,20 +655,122 @@ __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
         emit(std::false_type{}, idx, TAIL_WORDS / 2);
     }
     if (active && part == 0) A.nrej[b] = nrej;
+    if (A.flagged && blockIdx.x == 0 && threadIdx.x == 0) A.flagged[0] = 0;   // read by this prime's k_resolve_wave
+}
+
+// ------------------------------------------------------------------------------------------
+// Staged-LANE form (round 5): the bulk squeeze of ONE prime with one ciphertext per LANE -- phase 1 of
+// k_sample_uniform and nothing else (no candidate permutations inside the chain, no redraw phase, the seed is
+// dead after the absorb: ~100 VGPRs instead of 160).  Of a symmetric ciphertext's 606 chain permutations at n = 4096
+// only these 3 x 121 are sequential by the reference's semantics (sample.c:48-56); the 243 redraw candidates are
+// independent SHAKE calls and run as a phase-synchronised throughput kernel beside the chains (k_candidates over the
+// ciphertext's whole counter window), the resolve step is k_resolve_light / k_resolve_wave as in the pair form.
+// Writes residues / markers, the reject list and the reject count; same conventions as k_bulk_pair.
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(512) void k_bulk_lane(DevParams P, UniformArgs A)
+{
+    constexpr int N          = 1 << LOGN;
+    constexpr int FULL_STEPS = (N * 4) / 136;
+    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;
+    static_assert(TAIL_WORDS % 2 == 0 && TAIL_WORDS <= 32, "the tail fits one mask");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];   // reserved: one workgroup per CU
+    (void)pin_lds;
+    const size_t bq   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = bq < A.B;
+    if (A.flagged && bq == 0) A.flagged[0] = 0;   // read by this prime's k_resolve_wave
+    if (!__any(active)) return;
+    const size_t b   = active ? bq : (size_t)A.B - 1;   // idle lanes shadow the last ciphertext, store nothing
+    const uint32_t j = A.prime_lo;
+    const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
+    uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+    uint32_t *mylist = A.rej_list + b * A.rej_cap;
+    KeccakState st;
+    {
+        uint32_t seed[16];
+        load_seed(seed, A.seeds, b);
+        prng_absorb(st, seed, A.ctr_in ? A.ctr_in[b] : 0);
+    }
+    uint32_t nrej = 0;
+    if (active)
+    {
+        // branch-free reject test / reduction of a word and the per-step flush of the reject masks: see k_sample_uniform
+        auto word = [&](auto r4, uint32_t x, uint32_t &mask) -> uint32_t {
+            const bool rej   = x >= bound;
+            const uint32_t r = reduce_sample<decltype(r4)::value>(x, q, crh);
+            mask             = (mask << 1) | (rej ? 1u : 0u);
+            return rej ? kRejMarker : r;
+        };
+        const bool red4 = (uint64_t)bound <= 4ull * q;   // uniform per prime
+        auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
+            while (__any(mask != 0))
+            {
+                if (mask != 0)
+                {
+                    const uint32_t p = (uint32_t)__clz((int)mask);
+                    mask &= ~(0x80000000u >> p);
+                    if (nrej < A.rej_cap) mylist[nrej] = first_pos + (p - (32u - count));
+                    nrej++;
+                }
+            }
+        };
+        uint32_t idx = 0;
+        for (int step = 0; step < FULL_STEPS; step++)
+        {
+            keccak_f1600(st);
+            uint32_t m0 = 0, m1 = 0;   // words 0..31 / 32..33 of this step
+            auto emit = [&](auto r4) {
+#pragma unroll
+                for (int i = 0; i < 17; i++)
+                {
+                    uint32_t &mk = (i < 16) ? m0 : m1;
+                    uint32_t w0  = word(r4, st.lo[i], mk);
+                    uint32_t w1  = word(r4, st.hi[i], mk);
+                    *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+                }
+            };
+            if (red4)
+                emit(std::true_type{});
+            else
+                emit(std::false_type{});
+            if (__any((m0 | m1) != 0))
+            {
+                flush(m0, 32, idx);
+                flush(m1, 2, idx + 32);
+            }
+            idx += 34;
+        }
+        if constexpr (TAIL_WORDS > 0)
+        {
+            keccak_f1600(st);
+            uint32_t m0 = 0;
+#pragma unroll
+            for (int i = 0; i < TAIL_WORDS / 2; i++)
+            {
+                uint32_t w0 = word(std::false_type{}, st.lo[i], m0);
+                uint32_t w1 = word(std::false_type{}, st.hi[i], m0);
+                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+            }
+            flush(m0, TAIL_WORDS, idx);
+        }
+        A.nrej[b] = nrej;
+    }
 }
 
 // candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4]; consecutive threads = consecutive k of one ciphertext.
 // Round 4: 512-thread workgroups and the phase-synchronised permutation, as k_sample_cbd (-DSEAMD_CBD_NOSYNC: round 3).
-__global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A)
+// A launch covers candidates k_lo <= k < k_lo + k_cnt of every row of `stride` words (the staged-lane form fills a
+// ciphertext's window in a few launches, the earliest counters first).
+__global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A, uint32_t k_lo, uint32_t k_cnt, uint32_t stride)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)A.B * A.spec_cap;
+    const size_t total = (size_t)A.B * k_cnt;
 #ifndef SEAMD_CBD_NOSYNC
     if (!__any(gid < total)) return;   // whole waves past the end leave by a SCALAR branch, before the first barrier
 #endif
     if (gid >= total) return;          // lanes of a partial wave: masked, the wave runs the permutation
-    const size_t b   = gid / A.spec_cap;
-    const uint32_t k = (uint32_t)(gid - b * A.spec_cap);
+    const size_t b   = gid / k_cnt;
+    const uint32_t k = k_lo + (uint32_t)(gid - b * k_cnt);
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
     const uint64_t ctr = (A.ctr_in ? A.ctr_in[b] : 0) + 1 + k;
@@ -676,7 +778,7 @@ __global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A)
     KeccakState st;
     prng_absorb(st, seed, ctr);
     keccak_f1600_fresh<true>(st);   // only the first word is consumed
-    A.spec[gid] = st.lo[0];
+    A.spec[b * stride + k] = st.lo[0];
 #else
     uint32_t w[18];
 #pragma unroll
@@ -684,8 +786,28 @@ __global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A)
     w[16] = (uint32_t)ctr;
     w[17] = (uint32_t)(ctr >> 32);
     keccak_fresh4_sync(w, &kKeccakRC[0][0]);
-    A.spec[gid] = w[0];
+    A.spec[b * stride + k] = w[0];
 #endif
+}
+
+// The candidate row of ciphertext b for the prime that starts at counter c (its bulk block took c, the redraw
+// candidates are the counters c + 1, c + 2, ...): per-prime rows (k_candidates ran with this prime's start counters)
+// or, in the staged-lane form, the ciphertext's window from offset c on (UniformArgs::spec_window).
+__device__ __forceinline__ const uint32_t *candidate_row(const UniformArgs &A, size_t b, uint64_t c, uint32_t &row_len)
+{
+    if (!A.spec)
+    {
+        row_len = 0;
+        return nullptr;
+    }
+    if (A.spec_window == 0)
+    {
+        row_len = A.spec_cap;
+        return A.spec + b * (size_t)A.spec_cap;
+    }
+    const uint32_t off = c < (uint64_t)A.spec_window ? (uint32_t)c : A.spec_window;
+    row_len            = min(A.spec_cap, A.spec_window - off);
+    return A.spec + b * (size_t)A.spec_stride + off;
 }
 
 // The common case of the resolve step without any Keccak in the kernel (24 VGPRs instead of 130: 8 waves per
@@ -703,29 +825,38 @@ __global__ __launch_bounds__(256) void k_resolve_light(DevParams P, UniformArgs 
     const uint32_t j    = A.prime_lo;
     const uint32_t nrej = A.nrej[b];
     uint32_t need       = (A.debug_flags & 2) ? 0u : nrej;
-    uint64_t ctr        = (A.ctr_in ? A.ctr_in[b] : 0) + 1;   // the bulk block took one counter
-    const uint32_t rounds = (A.spec_cap + 63u) / 64u;
+    const uint64_t c0   = A.ctr_in ? A.ctr_in[b] : 0;
+    uint64_t ctr        = c0 + 1;   // the bulk block took one counter
+    uint32_t row_len;
+    const uint32_t *row   = candidate_row(A, b, c0, row_len);
+    const uint32_t rounds = (row_len + 63u) / 64u;
+    auto flag = [&]() {
+        if (lane == 0)
+        {
+            A.nrej[b] = nrej | 0x80000000u;
+            if (A.flagged) A.flagged[1 + atomicAdd(A.flagged, 1u)] = (uint32_t)b;
+        }
+    };
     if (need > A.rej_cap || rounds > 8u || !A.spec)
     {
-        if (lane == 0) A.nrej[b] = nrej | 0x80000000u;
+        flag();
         return;
     }
     const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
     uint32_t *mypoly       = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
     const uint32_t *mylist = A.rej_list + b * A.rej_cap;
-    const uint32_t *row    = A.spec + b * (size_t)A.spec_cap;
     const uint64_t lt      = (1ull << lane) - 1ull;
     uint32_t x[8];
 #pragma unroll
     for (int r = 0; r < 8; r++)
-        x[r] = ((uint32_t)r < rounds && 64u * r + (uint32_t)lane < A.spec_cap) ? row[64 * r + lane] : 0xFFFFFFFFu;
+        x[r] = ((uint32_t)r < rounds && 64u * r + (uint32_t)lane < row_len) ? row[64 * r + lane] : 0xFFFFFFFFu;
     uint32_t done = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++)
     {
         if (need > 0 && (uint32_t)r < rounds)
         {
-            const uint32_t cnt = min(64u, A.spec_cap - 64u * r);
+            const uint32_t cnt = min(64u, row_len - 64u * r);
             const bool acc     = (uint32_t)lane < cnt && x[r] < bound;
             const uint64_t am  = __ballot(acc);
             const uint32_t pre = (uint32_t)__popcll(am & lt);
@@ -742,7 +873,7 @@ __global__ __launch_bounds__(256) void k_resolve_light(DevParams P, UniformArgs 
     }
     if (need > 0)
     {
-        if (lane == 0) A.nrej[b] = nrej | 0x80000000u;   // row too short: k_resolve_wave redoes this ciphertext
+        flag();   // row too short: k_resolve_wave redoes this ciphertext
         return;
     }
     if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
@@ -753,23 +884,31 @@ __global__ __launch_bounds__(256) void k_resolve_wave(DevParams P, UniformArgs A
 {
     constexpr int N = 1 << LOGN;
     const int lane  = threadIdx.x & 63;
-    const size_t b  = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= A.B) return;   // wave-uniform
     const uint32_t j = A.prime_lo;
-    uint64_t ctr     = (A.ctr_in ? A.ctr_in[b] : 0) + 1;   // the bulk block took one counter
-    // after k_resolve_light: only the ciphertexts it flagged (top bit of the count) are left
-    const uint32_t raw = A.nrej[b];
-    if (A.master_waves == 1u && !(raw & 0x80000000u)) return;
-    const uint32_t need = (A.debug_flags & 2) ? 0u : (raw & 0x7FFFFFFFu);
-    if (need > 0)
+    // with a list of flagged ciphertexts: a small grid, every wave takes entries w, w + waves, ... of it
+    const size_t w0 = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), wstep = (size_t)gridDim.x * (blockDim.x >> 6);
+    const size_t count = A.flagged ? (size_t)A.flagged[0] : (size_t)A.B;
+    for (size_t w = w0; w < count; w += wstep)   // wave-uniform
     {
-        uint32_t seed[16];
-        load_seed(seed, A.seeds, b);
-        uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
-        wave_redraws<N>(P.q[j], P.cr_hi[j], P.bound[j], mypoly, A.rej_list + b * A.rej_cap, A.rej_cap, need, seed, ctr,
-                        A.spec ? A.spec + b * (size_t)A.spec_cap : nullptr, A.spec ? A.spec_cap : 0u, lane);
+        const size_t b    = A.flagged ? (size_t)A.flagged[1 + w] : w;
+        const uint64_t c0 = A.ctr_in ? A.ctr_in[b] : 0;
+        uint64_t ctr      = c0 + 1;   // the bulk block took one counter
+        // after k_resolve_light: only the ciphertexts it flagged (top bit of the count) are left
+        const uint32_t raw = A.nrej[b];
+        if (A.master_waves == 1u && !(raw & 0x80000000u)) continue;
+        const uint32_t need = (A.debug_flags & 2) ? 0u : (raw & 0x7FFFFFFFu);
+        if (need > 0)
+        {
+            uint32_t seed[16];
+            load_seed(seed, A.seeds, b);
+            uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+            uint32_t row_len;
+            const uint32_t *row = candidate_row(A, b, c0, row_len);
+            wave_redraws<N>(P.q[j], P.cr_hi[j], P.bound[j], mypoly, A.rej_list + b * A.rej_cap, A.rej_cap, need, seed, ctr,
+                            row, row_len, lane);
+        }
+        if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
     }
-    if (A.ctr_out && lane == 0) A.ctr_out[b] = ctr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1440,11 +1579,39 @@ hipError_t launch_uniform_bulk_pair(const DevParams &P, const UniformArgs &A, hi
     return hipGetLastError();
 }
 
-hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st)
+hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st, uint32_t k_lo, uint32_t k_cnt)
 {
-    const size_t total = (size_t)A.B * A.spec_cap;
+    if (k_cnt == 0xFFFFFFFFu) k_lo = 0, k_cnt = A.spec_cap;
+    const uint32_t stride = A.spec_window ? A.spec_stride : A.spec_cap;
+    const size_t total    = (size_t)A.B * k_cnt;
     if (total == 0 || !A.spec) return hipSuccess;
-    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A);
+    if (k_lo + k_cnt > stride) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A,
+                       k_lo, k_cnt, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_uniform_bulk_lane(const DevParams &P, const UniformArgs &A, hipStream_t st)
+{
+    if (A.B == 0) return hipSuccess;
+    if (!A.nrej || A.prime_hi != A.prime_lo + 1) return hipErrorInvalidValue;
+    unsigned threads, grid;
+    size_t lds;
+    chain_geometry(A.B, P.num_cus, threads, grid, lds);
+    if (threads > 512) return hipErrorInvalidValue;   // the form is for batches of up to 8 chain waves per CU
+#define SEAMD_LAUNCH_BULK_LANE(L)                                                                                  \
+    (void)hipFuncSetAttribute((const void *)k_bulk_lane<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_bulk_lane<L>), dim3(grid), dim3(threads), lds, st, P, A)
+    switch (P.logn)
+    {
+        case 10: SEAMD_LAUNCH_BULK_LANE(10); break;
+        case 11: SEAMD_LAUNCH_BULK_LANE(11); break;
+        case 12: SEAMD_LAUNCH_BULK_LANE(12); break;
+        case 13: SEAMD_LAUNCH_BULK_LANE(13); break;
+        case 14: SEAMD_LAUNCH_BULK_LANE(14); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef SEAMD_LAUNCH_BULK_LANE
     return hipGetLastError();
 }
 
@@ -1457,9 +1624,11 @@ hipError_t launch_uniform_resolve(const DevParams &P, const UniformArgs &A, hipS
     // light one ran -- picks up the flagged rest (normally none: its waves read one word and leave)
     UniformArgs H   = A;
     H.master_waves  = 1;
+    // with a flagged list: one workgroup per CU walks it (normally it is empty or a handful of entries)
+    const dim3 hgrid(A.flagged ? std::min<unsigned>((unsigned)((A.B + 3) / 4), P.num_cus ? P.num_cus : 256u) : grid.x);
 #define SEAMD_LAUNCH_RESOLVE(L)                                              \
     hipLaunchKernelGGL((k_resolve_light<L>), grid, block, 0, st, P, A);      \
-    hipLaunchKernelGGL((k_resolve_wave<L>), grid, block, 0, st, P, H)
+    hipLaunchKernelGGL((k_resolve_wave<L>), hgrid, block, 0, st, P, H)
     switch (P.logn)
     {
         case 10: SEAMD_LAUNCH_RESOLVE(10); break;

@@ -319,6 +319,47 @@ def test_staged_sampler_pipeline(env, shape, B):
         ctx.close()
 
 
+@pytest.mark.parametrize("shape,B", [((1024, 1), 70), ((4096, 3), 131), ((4096, 3), 1500), ((2048, 1), 513)],
+                         ids=lambda v: str(v))
+def test_staged_lane_sampler_phase(env, shape, B):
+    """The staged-LANE form of the symmetric sampler phase (round 5: k_bulk_lane -- one ciphertext per lane, only
+    the bulk squeeze in the chain --, the redraw candidates of all primes as ONE window of the ciphertext's counter
+    stream computed by the phase-synchronised k_candidates beside the chains, one light resolve per prime walking
+    the window from the prime's start counter; forced with debug flag 2048 in front of the fused kernel) against the
+    oracle: ragged batches (idle lanes, partial workgroups, a last candidate workgroup with few live lanes), a window
+    that is far too short (every ciphertext finished by k_resolve_wave with candidates it computes itself), a reject
+    list that is too short (marker scan), repeated calls on the same scratch."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = shape
+    o = Oracle(n, npr)
+    sk = V.secret_key(n, seed=23)
+    vals = V.bench_values(B, n, first=1700)
+    ss, sd = V.bench_seeds(B, first=1700)
+    from oracle import pyoracle
+    ok, e0, e1 = o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=pyoracle.host_threads())
+    assert ok
+    for spec_cap, rej_cap in ((None, None), (8, None), (None, 5), (1, 0)):
+        ctx = env["pkg"].Context(n, npr)
+        ctx.set_secret_key(sk)
+        ctx.set_pipeline(1, 0)
+        ctx.set_debug_flags(2048)
+        if spec_cap is not None:
+            ctx.set_speculation_capacity(spec_cap)
+        if rej_cap is not None:
+            ctx.set_reject_list_capacity(rej_cap)
+        for rep in range(2):
+            c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+            c1 = torch.zeros_like(c0)
+            st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+            ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, status=st)
+            torch.cuda.synchronize()
+            assert bool(st.all())
+            assert np.array_equal(host_u32(c1), e1), (spec_cap, rej_cap, rep)
+            assert np.array_equal(host_u32(c0), e0), (spec_cap, rej_cap, rep)
+        ctx.close()
+
+
 def test_sample_uniform_speculation_shortfall_path(env):
     """Helper waves precompute spec_cap redraw candidates per ciphertext; when a ciphertext needs
     more, the rest goes through the pooled loop.  Forced here with tiny capacities."""
@@ -1129,8 +1170,11 @@ def _compare_all_with_oracle(c0, c1, oracle_chunk, B, chunk=4096):
         del e1
 
 
-def test_full_size_properties_config2(env):
-    """BASELINE config 2 shape (n=4096, 3 primes) at a large batch: (a) the reference's own
+@pytest.mark.parametrize("form", ["dispatch", "lane_chain", "staged_lane"])
+def test_full_size_properties_config2(env, form):
+    """(form: the sampler phase the library's dispatch picks at this batch; forced to the one-launch lane chain
+    (debug flag 8192); forced to the staged-lane form of round 5 (2048) -- every ciphertext through each.)
+    BASELINE config 2 shape (n=4096, 3 primes) at a large batch: (a) the reference's own
     round-trip criterion c0 + c1*NTT(s) == NTT(m+e) exactly (ckks_tests_common.c:206) evaluated
     on the GPU outputs for EVERY ciphertext; (b) oracle spot checks on scattered records;
     (c) determinism: a second run gives identical bytes; (d) EXHAUSTIVE parity: all B ciphertexts
@@ -1141,6 +1185,7 @@ def test_full_size_properties_config2(env):
     n, npr = 4096, 3
     B = int(os.environ.get("SE_TEST_FULL_B", "65536"))   # BASELINE config 2 batch
     ctx = env["pkg"].Context(n, npr)
+    ctx.set_debug_flags({"dispatch": 0, "lane_chain": 8192, "staged_lane": 2048}[form])
     sk = V.secret_key(n)
     ctx.set_secret_key(sk)
     o = Oracle(n, npr)
