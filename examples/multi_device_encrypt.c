@@ -206,7 +206,7 @@ int main(int argc, char **argv)
     }
     /* how many different PCI devices did the group span? */
     size_t distinct = 0;
-    char bus[64][32];
+    char (*bus)[32] = (char (*)[32])calloc(ndev ? ndev : 1, 32);   /* the same device may be listed many times */
     for (size_t i = 0; i < ndev; i++)
     {
         char id[32] = "?";
@@ -215,6 +215,7 @@ int main(int argc, char **argv)
         while (k < distinct && strcmp(bus[k], id)) k++;
         if (k == distinct) strcpy(bus[distinct++], id);
     }
+    free(bus);
     int failed = 0;
     for (size_t i = 0; i < ndev; i++)
     {

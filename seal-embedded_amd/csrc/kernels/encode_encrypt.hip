@@ -264,6 +264,9 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     auto plain_ifft = [&]() {
 #ifdef SEAMD_NO_REAL_PASS0
         ifft_tiles<LOGN, false, false, kFastSync>(re, im, T.ifft_w, plane, t);
+#elif defined(SEAMD_SYM5)
+        // A/B: the fast fused forms at FIVE workgroups per CU -- exchanges through a 17 KiB half plane
+        ifft_tiles<LOGN, true, false, false, (sizeof(MT) == 4 && LOGN <= 12)>(re, im, T.ifft_w, plane, t);
 #else
         ifft_tiles<LOGN, true, false, kFastSync>(re, im, T.ifft_w, plane, t);  // real input: short butterflies in pass 0
 #endif
@@ -348,6 +351,8 @@ constexpr int enc_quad_stride()
 {
 #ifdef SEAMD_ASYM_SERIAL4
     return 20;
+#elif defined(SEAMD_SYM5)
+    return 28;   // the transpose region is aliased into the plane in that build: conflict-free rows fit
 #else
     return MODE == kModeAsym ? 28 : 20;
 #endif
@@ -418,7 +423,9 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     // trailing barrier; one workgroup barrier per prime keeps the next prime's first exchange off it): 51 KiB per
     // workgroup instead of 79, THREE workgroups per CU -- possible since the kernel needs 150 VGPRs (opaque_index
     // above; 206 before).  Fused stage 5.09 -> 4.83 ms per 65 536 (profiles/r04_ab_transform.log).
-#ifndef SEAMD_NO_ASYM3_ALIAS
+#if defined(SEAMD_SYM5)
+    constexpr bool QALIAS  = !GENERAL && LOGN <= 12 && (MODE != kModeAsym || ASYM3);
+#elif !defined(SEAMD_NO_ASYM3_ALIAS)
     constexpr bool QALIAS  = MODE == kModeAsym && ASYM3 && !GENERAL;
 #else
     constexpr bool QALIAS  = false;
@@ -576,6 +583,12 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             uint32_t a_pre[16];
             if constexpr (MODE == kModeSym && QUADS) ld_poly<QUADS>(a_pre, A.c1 + pb, tg);
 #endif
+#ifdef SEAMD_PREFETCH_PAIRS
+            // A/B: the (s_hat, shoup) pairs requested here as well (L2-resident; in the default form their round
+            // trip sits between the transform and the epilogue: 8 loads, then s_waitcnt 25 instructions later)
+            uint32_t w_pre[16], wp_pre[16];
+            if constexpr (MODE == kModeSym && QUADS) ld_pairs<QUADS>(w_pre, wp_pre, T.s_hat + kb, tg);
+#endif
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
             reduce_signed16(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
                                                                           // symmetric kernel keeps the exact form
@@ -611,7 +624,22 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
                 else
 #endif
                 ld_poly<QUADS>(a, A.c1 + pb, tg);
+#ifdef SEAMD_PREFETCH_PAIRS
+                if constexpr (QUADS)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) w[e] = w_pre[e], wp[e] = wp_pre[e];
+                }
+                else
+#endif
+#ifdef SEAMD_ABL_NOPAIRS   // timing ablation (WRONG results): what the key-pair loads of the symmetric epilogue cost
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) w[e] = 12345u + e + tg, wp[e] = 54321u * e;
+                }
+#else
                 ld_pairs<QUADS>(w, wp, T.s_hat + kb, tg);
+#endif
 #pragma unroll
                 for (int e = 0; e < 16; e++) out[e] = sub_mul_canon(x[e], a[e], w[e], wp[e], q, two_q);
                 st_poly<QUADS>(A.c0 + pb, out, tg);
@@ -620,6 +648,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             {
                 st_poly<QUADS>(A.c0 + pb, x, tg);
             }
+            if constexpr (QALIAS) __syncthreads();   // the transpose region is the next prime's exchange plane
         }
     }
 }
@@ -636,6 +665,12 @@ constexpr int enc_blocks()
     if (MODE == kModeAsym && !GENERAL) return 3;   // transpose region inside the planes (encrypt_one, QALIAS)
 #endif
     if (MODE == kModeAsym) return 2;   // 3 (with the transpose region aliased) spills: 5.45 -> 7.07 ms
+#ifdef SEAMD_ABL_SYM_BLOCKS   // A/B only: register budget of the symmetric / encode-only fast form for this many workgroups per CU
+    if (!GENERAL) return SEAMD_ABL_SYM_BLOCKS;
+#endif
+#ifdef SEAMD_SYM5
+    if (!GENERAL) return 5;
+#endif
     return GENERAL ? 3 : 4;
 }
 
@@ -1037,7 +1072,12 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
 #else
         const size_t ntt_planes = (size_t)(MODE == kModeAsym ? 3 : 1) * G::SLOTS * sizeof(uint32_t);
 #endif
-#ifndef SEAMD_NO_ASYM3_ALIAS
+#if defined(SEAMD_SYM5)
+        // half-plane encoder exchanges (sym / encode-only), transpose region aliased into the plane(s)
+        shmem_fast = MODE == kModeAsym ? std::max(planes, std::max(ntt_planes, quads)) : std::max(ntt_planes, quads);
+#elif !defined(SEAMD_NO_ASYM3_ALIAS) && !defined(SEAMD_ASYM_SERIAL4)
+        // public key: the transpose region is aliased into the three planes (encrypt_one, QALIAS); the serial A/B
+        // build (SEAMD_ASYM_SERIAL4) has no alias and takes the plane + region sizing below
         shmem_fast = MODE == kModeAsym ? std::max(planes, std::max(ntt_planes, quads)) : std::max(planes, ntt_planes + quads);
 #else
         shmem_fast = std::max(planes, ntt_planes + quads);

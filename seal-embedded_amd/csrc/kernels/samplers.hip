@@ -766,9 +766,11 @@ __global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A, uint3
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * k_cnt;
 #ifndef SEAMD_CBD_NOSYNC
-    if (!__any(gid < total)) return;   // whole waves past the end leave by a SCALAR branch, before the first barrier
+    if (!__any(gid < total)) return;   // whole waves past the end END before the first barrier ...
 #endif
-    if (gid >= total) return;          // lanes of a partial wave: masked, the wave runs the permutation
+    if (gid >= total) return;          // ... lanes of a partial wave are masked, the wave runs the permutation
+    // (hipcc folds the two tests into one exec-masked region with a branch to s_endpgm: either way a wave that does not
+    // run the block has ended -- the contract of keccak_sync.cuh, checked on the ISA by tests/test_keccak_sync.py)
     const size_t b   = gid / k_cnt;
     const uint32_t k = k_lo + (uint32_t)(gid - b * k_cnt);
     uint32_t seed[16];
@@ -1028,9 +1030,11 @@ __global__ __launch_bounds__(kCbdThreads) void k_sample_cbd(CbdArgs A)
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * A.blocks_per_ct;
 #ifndef SEAMD_CBD_NOSYNC
-    if (!__any(gid < total)) return;   // whole waves past the end leave by a SCALAR branch, before the first barrier
+    if (!__any(gid < total)) return;   // whole waves past the end END before the first barrier ...
 #endif
-    if (gid >= total) return;          // lanes of a partial wave: masked, the wave runs the permutation
+    if (gid >= total) return;          // ... lanes of a partial wave are masked, the wave runs the permutation
+    // (hipcc folds the two tests into one exec-masked region with a branch to s_endpgm: either way a wave that does not
+    // run the block has ended -- the contract of keccak_sync.cuh, checked on the ISA by tests/test_keccak_sync.py)
 #ifdef SEAMD_ABL_CBD_PRIO
     __builtin_amdgcn_s_setprio(SEAMD_ABL_CBD_PRIO);   // A/B only: CBD waves above the chain waves they share SIMDs with
 #endif
@@ -1306,7 +1310,7 @@ __global__ __launch_bounds__(kTernWg) void k_sample_ternary_window(TernaryArgs A
     const uint32_t k   = tid - ctl * W;    // counter of its window
     const size_t b0    = (size_t)blockIdx.x * cpw;
     const bool valid   = ctl < cpw && b0 + ctl < A.B;
-    if (!__any(valid)) return;             // whole waves without work leave before the first barrier (scalar branch)
+    if (!__any(valid)) return;             // whole waves without work END before the first barrier (keccak_sync.cuh)
     const size_t b     = valid ? b0 + ctl : (size_t)A.B - 1;
     const uint32_t n = A.n, nblocks = (n + 95) / 96, last = n - (nblocks - 1) * 96;
     int8_t *out = A.codes + b * n;

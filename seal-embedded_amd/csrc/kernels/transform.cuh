@@ -148,6 +148,21 @@ __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
     }
 }
 
+// An FP64 exchange through a buffer of HALF the size: the low and the high 32-bit words of the 16 values cross one
+// after the other through an XformGeom::SLOTS-word plane (twice the LDS instructions and barriers of the 64-bit form,
+// the same bytes).  What it buys is LDS capacity: the encoder's exchange buffer shrinks from 34 to 17 KiB at n = 4096.
+template <int C_FROM, int C_TO, RedealSync SYNC = kSyncBoth>
+__device__ __forceinline__ void redeal_halves(double (&v)[16], uint32_t *lds, int t)
+{
+    uint32_t lo[16], hi[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) lo[e] = (uint32_t)__double2loint(v[e]), hi[e] = (uint32_t)__double2hiint(v[e]);
+    redeal<C_FROM, C_TO, SYNC>(lo, lds, t);
+    redeal<C_FROM, C_TO, SYNC>(hi, lds, t);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = __hiloint2double((int)hi[e], (int)lo[e]);
+}
+
 // The window 4 -> 0 exchange as a register shuffle (north_star: "wavefront shuffle for the intra-64 twiddle
 // stages"): a 16 x 16 transpose of (slot, lane-within-row) among the 16 lanes of a DPP row -- four butterfly
 // stages, each swapping one slot bit with one lane bit: distance 8 and 4 by v_mov_b32_dpp row_shl / row_shr
@@ -411,7 +426,8 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
 // their barrier.  Precondition: a workgroup barrier separates the call from any earlier cross-wave use of
 // `plane`.  Postcondition: other waves may still be READING `plane` when a wave returns -- the next
 // cross-wave user of that memory must start with a barrier (kSyncLead, or any __syncthreads).
-template <int LOGN, bool REAL_IN = false, bool EXACT = false, bool FAST = false>
+// HALF (n <= 4096): the exchanges go through a plane of XformGeom::SLOTS 32-bit words (redeal_halves).
+template <int LOGN, bool REAL_IN = false, bool EXACT = false, bool FAST = false, bool HALF = false>
 __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
                                            const double *__restrict__ W, double *plane, int t)
 {
@@ -421,6 +437,19 @@ __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
         ifft_pass0_real<LOGN>(re, im, W, t);
     else
         ifft_pass<LOGN, 0, 0, 4, EXACT>(re, im, W, t);
+    if constexpr (HALF)
+    {
+        static_assert(LOGN <= 12 && !FAST, "half-plane exchanges: the three-pass transforms, plain synchronisation");
+        uint32_t *half = reinterpret_cast<uint32_t *>(plane);
+        constexpr int C2 = G::ifft_c(2);
+        redeal_halves<0, 4>(re, half, t);
+        redeal_halves<0, 4>(im, half, t);
+        ifft_pass<LOGN, 4, 0, 4, EXACT>(re, im, W, t);
+        redeal_halves<4, C2>(re, half, t);
+        redeal_halves<4, C2>(im, half, t);
+        ifft_pass<LOGN, C2, 8 - C2, 4, EXACT>(re, im, W, t);
+        return;
+    }
     redeal<0, 4, FIRST>(re, plane, t);
     redeal<0, 4, FIRST>(im, plane, t);
     ifft_pass<LOGN, 4, 0, 4, EXACT>(re, im, W, t);

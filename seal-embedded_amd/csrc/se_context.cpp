@@ -83,6 +83,8 @@ Context::~Context()
     if (cand_stream) (void)hipStreamDestroy(cand_stream);
     for (auto &e : ev_cand)
         if (e) (void)hipEventDestroy(e);
+    // nothing may still be writing the scratch when it is wiped (the streams above were non-blocking)
+    (void)hipDeviceSynchronize();
     // secret-bearing slabs are zeroed before they go back to the allocator: NTT(s), the error polynomials
     // e / e0|e1, the ternary u, the per-ciphertext seeds of the speculation path and `a` (recomputable from the
     // shareable seed, kept out of freed memory all the same)

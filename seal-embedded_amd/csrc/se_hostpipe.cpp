@@ -104,15 +104,29 @@ static bool is_pinned(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
+// the device slots hold PRNG seeds, plaintext values and m + e between calls: zeroed before they go back to the
+// allocator (callers have drained the streams that used them)
 static int regrow(void **p, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return 0;
-    if (*p) (void)hipFree(*p);
+    if (*p)
+    {
+        (void)hipMemset(*p, 0, *cap);
+        (void)hipFree(*p);
+    }
     *p   = nullptr;
     *cap = 0;
     SEAMD_HIP(hipMalloc(p, bytes));
     *cap = bytes;
     return 0;
+}
+
+// zero the secret-bearing buffers of a slot (s.cap ciphertexts: seeds of e / u, the shareable seed, plaintext values)
+void HostPipe::wipe_slot(Slot &s)
+{
+    if (s.seeds) (void)hipMemset(s.seeds, 0, s.cap * 64);
+    if (s.share_seeds) (void)hipMemset(s.share_seeds, 0, s.cap * 64);
+    if (s.values) (void)hipMemset(s.values, 0, s.cap * values_bytes_per_ct);
 }
 
 HostPipe::~HostPipe()
@@ -122,6 +136,10 @@ HostPipe::~HostPipe()
     if (copy) (void)hipStreamSynchronize(copy);
     for (auto &s : slot)
     {
+        // secret-bearing slots (seeds of e / u, the shareable seed, values, m + e) are wiped first
+        wipe_slot(s);
+        if (s.pte) (void)hipMemset(s.pte, 0, s.cap_pte);
+        (void)hipDeviceSynchronize();
         void *ptrs[] = {s.values, s.seeds, s.share_seeds, s.c0, s.c1, s.ntt_pte, s.pte};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -130,7 +148,11 @@ HostPipe::~HostPipe()
     }
     for (int r = 0; r < kRing; r++)
     {
-        if (ring[r]) (void)hipHostFree(ring[r]);
+        if (ring[r])
+        {
+            explicit_bzero(ring[r], ring_bytes);   // the pinned staging ring carried m + e / ciphertext pieces
+            (void)hipHostFree(ring[r]);
+        }
         if (ring_ev[r]) (void)hipEventDestroy(ring_ev[r]);
     }
     if (d_status) (void)hipFree(d_status);
@@ -164,6 +186,8 @@ int HostPipe::ensure(Context &c, size_t chunk, size_t B, bool want_ntt, bool wan
     {
         if (chunk > s.cap)
         {
+            wipe_slot(s);
+            values_bytes_per_ct = (n / 2) * sizeof(float);
             void **ptrs[] = {&s.values, &s.seeds, &s.share_seeds, &s.c0, &s.c1};
             for (void **p : ptrs)
                 if (*p)
@@ -194,7 +218,11 @@ int HostPipe::ensure(Context &c, size_t chunk, size_t B, bool want_ntt, bool wan
         {
             for (int r = 0; r < kRing; r++)
             {
-                if (ring[r]) (void)hipHostFree(ring[r]);
+                if (ring[r])
+                {
+                    explicit_bzero(ring[r], ring_bytes);
+                    (void)hipHostFree(ring[r]);
+                }
                 ring[r] = nullptr;
             }
             ring_bytes = 0;

@@ -72,6 +72,8 @@ struct HostPipe
     hipStream_t compute = nullptr, copy = nullptr;
     CopyPool *pool      = nullptr;
     size_t chunk_override = 0;  // test hook: ciphertexts per chunk (0 = automatic)
+    size_t values_bytes_per_ct = 0;   // (n / 2) floats: size of one ciphertext's slice of Slot::values
+    void wipe_slot(Slot &s);          // zero the seeds / values a slot holds (before it is freed or regrown)
 
     ~HostPipe();
     int init(int device);

@@ -79,7 +79,52 @@ struct Lower
     uint32_t *fail   = nullptr;                      // [1]
     uint8_t *bytes   = nullptr;                      // growable raw buffer (prng_fill_buffer)
     size_t bytes_cap = 0;
+    std::vector<uint32_t> roots_cache[seamd::kMaxPrimes];   // ntt_roots_initialize output per prime (host table)
     Context &c() { return h->c; }
+
+    // ---- symmetric fast path (round 5) -------------------------------------------------------------------------
+    // ckks_sym_init (ckks_sym.c:181-197) receives the shareable seed: from there on a_j of EVERY prime is a function of
+    // (seed, start counter of prime j), and the start counter of prime j >= 1 lies in a narrow window (se_context.cpp,
+    // small_batch_plan).  So the init call launches, asynchronously, the uniform sampler of prime 0 at counter 0 and of
+    // every prime j >= 1 for every start counter of its window ("virtual ciphertexts", one wave each, ONE launch) -- the
+    // primes of a ciphertext run side by side instead of as np sequential 121-permutation chains, as se_encrypt_seeded
+    // does.  The first ckks_encode_encrypt_sym call (ckks_sym.c:199) that finds its PRNG state in that table follows
+    // the counter chain through it on the host, launches the per-prime kernel for this AND the remaining primes, and
+    // every per-prime call returns its prime from the precomputed results WHEN ITS INPUTS MATCH what they were computed
+    // from: shareable seed and counter, plaintext (m + e) and packed key compared byte for byte, no ep_small.  Anything
+    // else takes the per-prime chain as before.  PRNG counters are left exactly as the reference leaves them.
+    struct SymSpec
+    {
+        bool armed = false, fetched = false;
+        uint8_t seed[64] = {};
+        // The chain follows the caller's prime order: it starts at the prime the Parms stood at when ckks_sym_init was
+        // called (the reference's bench_sym never rewinds: its iterations start at primes 0, 2, 1, 0, ...) and walks
+        // next_modulus's wrap-around order.  Step k of the chain = prime (first + k) mod chain; base / count / offset
+        // are indexed by STEP.
+        uint32_t first = 0, chain = 0;                   // prime of step 0; primes in the caller's chain
+        uint32_t nprimes = 0, total = 0;                 // steps covered; virtual ciphertexts (index 0: step 0 @ 0)
+        uint64_t base[seamd::kMaxPrimes]  = {};
+        uint32_t count[seamd::kMaxPrimes] = {}, offset[seamd::kMaxPrimes] = {};
+        uint32_t prime_of_step(uint32_t k) const { return (first + k) % chain; }
+        uint32_t step_of_prime(uint32_t j) const { return (j + chain - first) % chain; }
+        size_t cap = 0;                                  // virtual ciphertexts the device buffers hold
+        uint8_t *d_meta = nullptr;                       // [cap] x (64 seed + 8 ctr + 8 ctrout + 1 prime), carved below
+        uint8_t *d_seeds = nullptr, *d_prime = nullptr;
+        uint64_t *d_ctr = nullptr, *d_ctrout = nullptr;
+        uint32_t *d_rows = nullptr;                      // [cap][n]
+        std::vector<uint64_t> h_ctrout;
+        hipStream_t st = nullptr, cp = nullptr;
+        hipEvent_t ev_sampled = nullptr, ev_kernel[seamd::kMaxPrimes] = {}, ev_copied[seamd::kMaxPrimes] = {};
+        // precomputed primes
+        bool pre[seamd::kMaxPrimes]          = {};
+        uint64_t pre_start[seamd::kMaxPrimes] = {}, pre_end[seamd::kMaxPrimes] = {};
+        std::vector<int64_t> h_pte;                      // the plaintext d_pte holds (empty: none)
+        std::vector<uint8_t> h_key;                      // the packed key d_key holds
+        int64_t *d_pte  = nullptr;                       // [n]
+        uint8_t *d_key  = nullptr;                       // [n/4]
+        uint32_t *d_out = nullptr;                       // [np][3][n]: c0 | ntt_pte | s_save
+        uint32_t *h_stage = nullptr;                     // pinned [np][4][n]: a | c0 | ntt_pte | s_save
+    } sym;
 };
 
 std::map<size_t, Lower *> g_lower;
@@ -112,6 +157,31 @@ void lower_shutdown()
             (void)hipDeviceSynchronize();
             if (L->slab) (void)hipFree(L->slab);
             if (L->bytes) (void)hipFree(L->bytes);
+            Lower::SymSpec &S = L->sym;
+            const size_t n = L->n, np = L->c().hp.nprimes;
+            if (S.d_rows) (void)hipMemset(S.d_rows, 0, S.cap * n * sizeof(uint32_t));
+            if (S.d_meta) (void)hipMemset(S.d_meta, 0, S.cap * 88);
+            if (S.d_pte) (void)hipMemset(S.d_pte, 0, 8 * n);
+            if (S.d_key) (void)hipMemset(S.d_key, 0, n / 4);
+            if (S.d_out) (void)hipMemset(S.d_out, 0, np * 3 * n * sizeof(uint32_t));
+            (void)hipDeviceSynchronize();
+            void *dev[] = {S.d_rows, S.d_meta, S.d_pte, S.d_key, S.d_out};
+            for (void *q : dev)
+                if (q) (void)hipFree(q);
+            if (S.h_stage)
+            {
+                memset(S.h_stage, 0, np * 4 * n * sizeof(uint32_t));
+                (void)hipHostFree(S.h_stage);
+            }
+            if (!S.h_pte.empty()) explicit_bzero(S.h_pte.data(), S.h_pte.size() * 8);
+            if (!S.h_key.empty()) explicit_bzero(S.h_key.data(), S.h_key.size());
+            if (S.st) (void)hipStreamDestroy(S.st);
+            if (S.cp) (void)hipStreamDestroy(S.cp);
+            if (S.ev_sampled) (void)hipEventDestroy(S.ev_sampled);
+            for (auto &e : S.ev_kernel)
+                if (e) (void)hipEventDestroy(e);
+            for (auto &e : S.ev_copied)
+                if (e) (void)hipEventDestroy(e);
         }
         se_amd_destroy(L->h);
         delete L;
@@ -566,7 +636,18 @@ static void roots_generic(const Parms *parms, ZZ *roots, bool inverse)
     if (inverse)
         seamd::host_intt_root_pairs(L.c().hp, parms->curr_modulus_idx, rw);
     else
-        seamd::host_ntt_root_pairs(L.c().hp, parms->curr_modulus_idx, rw);
+    {
+        // the per-prime encrypt calls hand this table out every time (ckks_sym.c:270, one-shot roots): keep it
+        std::vector<uint32_t> &cache = L.roots_cache[parms->curr_modulus_idx];
+        if (cache.empty())
+        {
+            seamd::host_ntt_root_pairs(L.c().hp, parms->curr_modulus_idx, rw);
+            cache.resize(L.n);
+            for (size_t i = 0; i < L.n; i++) cache[i] = rw[2 * i];
+        }
+        memcpy(roots, cache.data(), L.n * sizeof(ZZ));
+        return;
+    }
     for (size_t i = 0; i < L.n; i++) roots[i] = rw[2 * i];
 }
 
@@ -607,6 +688,7 @@ void intt_inpl(const Parms *parms, const ZZ *intt_roots, ZZ *vec)
 static void uniform_on_device(Lower &L, const Parms *parms, SE_PRNG *prng)
 {
     Context &c       = L.c();
+    if (L.sym.armed && L.sym.st) LOWER_HIP(hipStreamSynchronize(L.sym.st));   // the speculation shares c.d_rej / c.d_spec
     const uint32_t j = (uint32_t)prime_of(parms);
     put_prng(L, prng);
     seamd::UniformArgs ua{L.seed, L.ctr, L.ctr + 1, L.u32[0], c.d_rej, c.rej_cap, 1, j, j + 1, 1,
@@ -816,12 +898,138 @@ void ckks_setup_s(const Parms *parms, uint8_t *seed, SE_PRNG *prng, ZZ *s)
         load_sk(parms, s);
 }
 
+// ---- symmetric fast path (Lower::SymSpec) ----
+static const size_t kSymSpecMaxBytes = (size_t)128 << 20;   // rows of the virtual ciphertexts
+
+// windows of the start counters of primes 1 .. np-1 (the estimate of Context::small_batch_plan), as many primes as the
+// row budget allows; launches the samplers on S.st.  The caller holds g_mu.
+static void sym_spec_arm(Lower &L, const Parms *parms, const SE_PRNG *shareable)
+{
+    Lower::SymSpec &S = L.sym;
+    Context &c        = L.c();
+    const size_t n    = L.n;
+    S.armed = S.fetched = false;
+    for (auto &p : S.pre) p = false;
+    if (getenv("SE_AMD_LOWER_SPECULATION") && atoi(getenv("SE_AMD_LOWER_SPECULATION")) == 0) return;
+    if (parms->nprimes < 1 || parms->nprimes > c.hp.nprimes) return;
+    LOWER_HIP(hipSetDevice(c.device));
+    if (!S.st)
+    {
+        LOWER_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+        LOWER_HIP(hipStreamCreateWithFlags(&S.cp, hipStreamNonBlocking));
+        LOWER_HIP(hipEventCreateWithFlags(&S.ev_sampled, hipEventDisableTiming));
+        for (auto &e : S.ev_kernel) LOWER_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : S.ev_copied) LOWER_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const size_t np = c.hp.nprimes;
+        LOWER_HIP(hipMalloc((void **)&S.d_pte, 8 * n));
+        LOWER_HIP(hipMalloc((void **)&S.d_key, n / 4));
+        LOWER_HIP(hipMalloc((void **)&S.d_out, np * 3 * n * sizeof(uint32_t)));
+        LOWER_HIP(hipHostMalloc((void **)&S.h_stage, np * 4 * n * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    else
+    {
+        LOWER_HIP(hipStreamSynchronize(S.st));   // an earlier speculation nobody consumed
+        LOWER_HIP(hipStreamSynchronize(S.cp));
+    }
+    // plan
+    double mu = 0.0, var = 0.0;
+    uint32_t total = 1, covered = 1;
+    S.first = (uint32_t)parms->curr_modulus_idx, S.chain = (uint32_t)parms->nprimes;
+    S.base[0] = 0, S.count[0] = 1, S.offset[0] = 0;
+    for (uint32_t j = 1; j < parms->nprimes; j++)
+    {
+        const double p = (double)(0u - c.dp.bound[S.prime_of_step(j - 1)]) / 4294967296.0;
+        mu += 1.0 + (double)n * p / (1.0 - p);
+        var += (double)n * p * 1.06;
+        const uint64_t h   = (uint64_t)(5.5 * sqrt(var)) + 2;
+        const uint64_t mid = (uint64_t)(mu + 0.5);
+        const uint32_t cnt = (uint32_t)(2 * h + 1);
+        if (((size_t)total + cnt) * n * sizeof(uint32_t) > kSymSpecMaxBytes) break;   // later primes: the plain chain
+        S.base[j]   = mid > h ? mid - h : 0;
+        S.count[j]  = cnt;
+        S.offset[j] = total;
+        total += cnt;
+        covered = j + 1;
+    }
+    if (total > S.cap)
+    {
+        if (S.d_rows) (void)hipFree(S.d_rows);
+        if (S.d_meta) (void)hipFree(S.d_meta);
+        S.d_rows = nullptr, S.d_meta = nullptr, S.cap = 0;
+        LOWER_HIP(hipMalloc((void **)&S.d_rows, (size_t)total * n * sizeof(uint32_t)));
+        LOWER_HIP(hipMalloc((void **)&S.d_meta, (size_t)total * 88));
+        S.cap      = total;
+        S.d_seeds  = S.d_meta;
+        S.d_ctr    = (uint64_t *)(S.d_meta + (size_t)total * 64);
+        S.d_ctrout = S.d_ctr + total;
+        S.d_prime  = (uint8_t *)(S.d_ctrout + total);
+    }
+    if (c.ensure_scratch(1, (size_t)1 + total) != 0) die("GPU scratch");
+    // seeds | counters | (end counters) | primes of the virtual ciphertexts: one upload
+    std::vector<uint8_t> meta((size_t)S.cap * 88, 0);
+    uint64_t *hc = (uint64_t *)(meta.data() + (size_t)S.cap * 64);
+    uint8_t *hp  = meta.data() + (size_t)S.cap * 80;
+    for (uint32_t j = 0; j < covered; j++)
+        for (uint32_t g = 0; g < S.count[j]; g++)
+        {
+            const uint32_t v = S.offset[j] + g;
+            memcpy(meta.data() + (size_t)v * 64, shareable->seed, 64);
+            hc[v] = S.base[j] + g;
+            hp[v] = (uint8_t)S.prime_of_step(j);
+        }
+    up(S.d_meta, meta.data(), meta.size());
+    explicit_bzero(meta.data(), meta.size());
+    seamd::UniformArgs ug{S.d_seeds, S.d_ctr, S.d_ctrout, S.d_rows, c.d_rej + c.rej_cap, c.rej_cap, total,
+                          0,         0,       1,          c.d_spec + c.spec_cap, c.spec_cap, 0, c.debug_flags,
+                          nullptr,   0,       0,          S.d_prime};
+    LOWER_HIP(seamd::launch_sample_uniform(c.dp, ug, S.st));
+    LOWER_HIP(hipEventRecord(S.ev_sampled, S.st));
+    memcpy(S.seed, shareable->seed, 64);
+    S.nprimes = covered;
+    S.total   = total;
+    S.armed   = true;
+}
+
+// row of the table that holds a_j for (this PRNG state, prime j), or -1
+static long sym_spec_row(Lower &L, const SE_PRNG *shareable, uint32_t j)
+{
+    Lower::SymSpec &S = L.sym;
+    if (!S.armed || j >= S.chain || memcmp(S.seed, shareable->seed, 64) != 0) return -1;
+    const uint32_t k = S.step_of_prime(j);
+    if (k >= S.nprimes) return -1;
+    const uint64_t g = shareable->counter - S.base[k];   // wraps to a huge value below the window
+    if (g >= S.count[k]) return -1;
+    return (long)(S.offset[k] + g);
+}
+
 void ckks_sym_init(const Parms *parms, uint8_t *share_seed_in, uint8_t *seed_in, SE_PRNG *shareable_prng,
                    SE_PRNG *prng, int64_t *conj_vals_int)
 {
     prng_randomize_reset(shareable_prng, share_seed_in);
     prng_randomize_reset(prng, seed_in);
-    sample_add_poly_cbd_generic_inpl_prng_16(conj_vals_int, parms->coeff_count, prng);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Lower &L = lower_for_degree(parms->coeff_count);
+    if (parms->moduli && parms->nprimes <= L.c().hp.nprimes && parms->curr_modulus_idx < parms->nprimes)
+        sym_spec_arm(L, parms, shareable_prng);
+    Lower::SymSpec &S = L.sym;
+    if (!S.armed)
+    {
+        sample_add_poly_cbd_generic_inpl_prng_16(conj_vals_int, parms->coeff_count, prng);
+        return;
+    }
+    // sample_add_poly_cbd_generic_inpl_prng_16 with the sum left in a buffer of its own: m + e stays on the device
+    // for the per-prime calls (L.i64 is every operator's scratch)
+    const size_t n = L.n;
+    put_prng(L, prng);
+    up(S.d_pte, conj_vals_int, 8 * n);
+    seamd::CbdArgs ca{L.seed, L.ctr, L.i8[0], (uint32_t)(n / 16), 1};
+    LOWER_HIP(seamd::launch_sample_cbd(ca, nullptr));
+    LOWER_HIP(seamd::launch_add_small(S.d_pte, L.i8[0], n, nullptr));
+    down(conj_vals_int, S.d_pte, 8 * n);   // host-synchronous: the sum is complete before anything on S.st reads it
+    S.h_pte.assign(conj_vals_int, conj_vals_int + n);
+    const uint64_t before = prng->counter;
+    prng->counter += n / 16;
+    after_draws(prng, before);
 }
 
 void ckks_encode_encrypt_sym(const Parms *parms, const int64_t *conj_vals_int, const int8_t *ep_small,
@@ -837,6 +1045,78 @@ void ckks_encode_encrypt_sym(const Parms *parms, const int64_t *conj_vals_int, c
         exit(1);
     }
     LOWER_HIP(hipSetDevice(L.c().device));
+    Lower::SymSpec &S = L.sym;
+    const uint32_t j  = (uint32_t)prime_of(parms);
+    long row          = ep_small ? -1 : sym_spec_row(L, shareable_prng, j);
+    if (row >= 0)
+    {
+        // ---- fast path: a_j comes from the table the init call started ----
+        if (!S.fetched)
+        {
+            LOWER_HIP(hipEventSynchronize(S.ev_sampled));
+            S.h_ctrout.resize(S.total);
+            down(S.h_ctrout.data(), S.d_ctrout, (size_t)S.total * 8);
+            S.fetched = true;
+        }
+        const bool same_pte = S.h_pte.size() == n && memcmp(S.h_pte.data(), conj_vals_int, 8 * n) == 0;
+        const bool same_key = S.h_key.size() == n / 4 && memcmp(S.h_key.data(), s_small, n / 4) == 0;
+        if (!(S.pre[j] && S.pre_start[j] == shareable_prng->counter && same_pte && same_key))
+        {
+            // (re)compute this prime and the ones the counter chain leads to, from the inputs of THIS call
+            LOWER_HIP(hipStreamSynchronize(S.cp));   // staging buffers of an earlier chain may still be in flight
+            for (auto &p : S.pre) p = false;
+            if (!same_pte)
+            {
+                up(S.d_pte, conj_vals_int, 8 * n);
+                S.h_pte.assign(conj_vals_int, conj_vals_int + n);
+            }
+            if (!same_key)
+            {
+                up(S.d_key, s_small, n / 4);
+                S.h_key.assign((const uint8_t *)s_small, (const uint8_t *)s_small + n / 4);
+            }
+            uint64_t ctr = shareable_prng->counter;
+            long r       = row;
+            // steps of the chain from this prime on; results are kept per PRIME (pr)
+            for (uint32_t k = S.step_of_prime(j); k < S.nprimes && r >= 0; k++)
+            {
+                const uint32_t pr = S.prime_of_step(k);
+                uint32_t *out = S.d_out + (size_t)pr * 3 * n, *stage = S.h_stage + (size_t)pr * 4 * n;
+                const uint32_t *a = S.d_rows + (size_t)r * n;
+                seamd::LowerSymArgs sa{S.d_key, S.d_pte, nullptr, a, out, out + n, out + 2 * n, (int)pr, 0, 0, 0};
+                LOWER_HIP(seamd::launch_lower_sym_prime(L.c().dp, L.c().dt, sa, 1, S.st));
+                LOWER_HIP(hipEventRecord(S.ev_kernel[pr], S.st));
+                LOWER_HIP(hipStreamWaitEvent(S.cp, S.ev_kernel[pr], 0));
+                LOWER_HIP(hipMemcpyAsync(stage, a, 4 * n, hipMemcpyDeviceToHost, S.cp));
+                LOWER_HIP(hipMemcpyAsync(stage + n, out, 3 * 4 * n, hipMemcpyDeviceToHost, S.cp));
+                LOWER_HIP(hipEventRecord(S.ev_copied[pr], S.cp));
+                S.pre[pr]       = true;
+                S.pre_start[pr] = ctr;
+                S.pre_end[pr]   = S.h_ctrout[r];
+                // the next prime starts where this one's redraws stopped
+                ctr = S.h_ctrout[r];
+                r   = -1;
+                if (k + 1 < S.nprimes)
+                {
+                    const uint64_t g = ctr - S.base[k + 1];
+                    if (g < S.count[k + 1]) r = (long)(S.offset[k + 1] + g);
+                }
+            }
+        }
+        LOWER_HIP(hipEventSynchronize(S.ev_copied[j]));
+        const uint32_t *stage = S.h_stage + (size_t)j * 4 * n;
+        // deliveries in the reference's write order, so that aliased buffers end up the same
+        memcpy(c1, stage, 4 * n);
+        if (c1_save) memcpy(c1_save, stage, 4 * n);
+        if (ntt_roots) roots_generic(parms, ntt_roots, false);
+        if (s_save) memcpy(s_save, stage + 3 * n, 4 * n);
+        memcpy(ntt_pte, stage + 2 * n, 4 * n);
+        memcpy(c0_s, stage + n, 4 * n);
+        const uint64_t before   = shareable_prng->counter;
+        shareable_prng->counter = S.pre_end[j];
+        after_draws(shareable_prng, before);
+        return;
+    }
     // c1 = a <- U (ckks_sym.c:220); the counter moves exactly as the reference's rejection loop
     uniform_on_device(L, parms, shareable_prng);
     up(L.packed, s_small, n / 4);

@@ -76,7 +76,16 @@ private:
             std::function<void()> job = std::move(job_);
             job_                      = nullptr;
             l.unlock();
-            job();
+            // a long-lived library thread must not take the process down: the job reports its own errors through
+            // its captured result slot; anything it throws (bad_alloc while building a message ...) is swallowed here
+            // and leaves that slot at the failure value it was initialised with
+            try
+            {
+                job();
+            }
+            catch (...)
+            {
+            }
             l.lock();
             busy_ = false;
             cv_.notify_all();
@@ -226,8 +235,10 @@ int run_group(se_amd_group *g, Mode mode, size_t B, const float *const *d_values
         }
     }
     std::lock_guard<std::mutex> one_call(g->call);
-    std::vector<int> rcs(ndev, SE_SUCCESS);
-    std::vector<std::string> errs(ndev);
+    // a member's slot starts at "failed": only a job that ran to its end overwrites it (Worker::loop swallows what a
+    // job throws so that a library thread never ends the process)
+    std::vector<int> rcs(ndev, SE_ERR_HIP);
+    std::vector<std::string> errs(ndev, "the member's worker thread did not finish its job (exception)");
     for (size_t i = 1; i < ndev; i++)
         g->worker[i - 1]->submit([&, i] {
             rcs[i] = run_member(g, i, mode, B, d_values, d_share_seeds, d_seeds, d_c0, d_c1, d_status, gather_root,

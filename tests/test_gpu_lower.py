@@ -372,3 +372,123 @@ def test_pool_carving_is_the_reference_default_layout(env):
             assert off["index_map_ptr"] == 5 * n and off["ternary"] == 5 * n + n // 2
             assert off["values"] == 5 * n + n // 2 + n // 16
         assert max(v for v in off.values() if v is not None) < size
+
+
+@pytest.mark.parametrize("shape", [(4096, 3), (8192, 6), (1024, 1)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_lower_sym_fast_path_keeps_the_reference_bytes_when_inputs_move(env, shape, monkeypatch):
+    """Round 5: ckks_sym_init (ckks_sym.c:181-197) starts the uniform samplers of ALL primes asynchronously (prime
+    speculation), the first ckks_encode_encrypt_sym (ckks_sym.c:199-301) computes every prime of the ciphertext, later
+    per-prime calls return their prime from that -- IF their inputs still match.  Every call here is compared with what
+    the reference computes from the inputs of THAT call: the plain sequence; the shareable PRNG's counter moved between
+    two primes (inside and far outside the speculated window); a plaintext coefficient changed between two primes; the
+    key changed; the PRNG re-seeded; a prime repeated; the gen_pk form (ep_small) in between; and the whole sequence
+    again with SE_AMD_LOWER_SPECULATION=0 (same bytes)."""
+    from oracle.pyoracle import Oracle
+    L = _lower(env)
+    n, npr = shape
+    o = Oracle(n, npr)
+    rng = np.random.default_rng(7 * n + npr)
+    seeds = V.derive_seeds(f"lower-fast-{n}", 4)
+    sk = V.secret_key(n, seed=29)
+    sk2 = V.secret_key(n, seed=31)
+
+    def one_prime(P, pte, pr, key, j, ep=None):
+        """call + check of one ckks_encode_encrypt_sym against the oracle's per-stage functions"""
+        c0, c1, ntt_pte = (np.zeros(n, np.uint32) for _ in range(3))
+        s_save, c1_save, roots = (np.zeros(n, np.uint32) for _ in range(3))
+        start = int(pr.counter)
+        sd = bytes(pr.seed)
+        L.ckks_encode_encrypt_sym(C.byref(P), None if ep is not None else _vp(pte), None if ep is None else _vp(ep),
+                                  C.byref(pr), _vp(key), _vp(ntt_pte), _vp(roots), _vp(c0), _vp(c1), _vp(s_save),
+                                  _vp(c1_save))
+        a, ectr = o.sample_uniform(j, sd, start)
+        q = int(o.p.q[j])
+        s_hat = o.ntt(o.expand_ternary(key, j), j)
+        x = o.ntt(o.reduce_pte(pte, j) if ep is None else o.reduce_e_small(ep, j), j)
+        ec0 = (x.astype(np.uint64) + q - (a.astype(np.uint64) * s_hat.astype(np.uint64)) % q) % q
+        assert pr.counter == ectr, (j, start)
+        assert (c1 == a).all() and (c1_save == a).all(), (j, start)
+        assert (s_save == s_hat).all() and (ntt_pte == x).all() and (roots == o.ntt_roots(j)).all(), (j, start)
+        assert (c0 == ec0.astype(np.uint32)).all(), (j, start)
+
+    def sequence():
+        P = Parms()
+        imap = np.zeros(n, np.uint16)
+        L.ckks_setup(C.c_size_t(n), C.c_size_t(npr), _vp(imap), C.byref(P))
+        m = rng.integers(-2 ** 30, 2 ** 30, n, dtype=np.int64)
+
+        def init(seed_a, seed_e):
+            pte = m.copy()
+            pa, pe = Prng(), Prng()
+            sa = np.frombuffer(bytes(seed_a), np.uint8).copy()
+            se = np.frombuffer(bytes(seed_e), np.uint8).copy()
+            L.ckks_sym_init(C.byref(P), _vp(sa), _vp(se), C.byref(pa), C.byref(pe), _vp(pte))
+            em, ectr = o.cbd_add(m, bytes(seed_e), 0)
+            assert (pte == em).all() and pe.counter == ectr and pa.counter == 0 and bytes(pa.seed) == bytes(seed_a)
+            return pte, pa
+
+        def rewind():
+            while P.curr_modulus_idx != 0:
+                L.next_modulus(C.byref(P))
+
+        # 1. the plain sequence, twice (the second init re-arms the table while the first one's results are around)
+        for rep in range(2):
+            pte, pa = init(seeds[rep], seeds[2])
+            for j in range(npr):
+                one_prime(P, pte, pa, sk, j)
+                if j + 1 < npr:
+                    assert L.next_modulus(C.byref(P))
+            rewind()
+        if npr == 1:
+            pte, pa = init(seeds[0], seeds[2])
+            pa.counter = 3                       # not the counter the table was built for
+            one_prime(P, pte, pa, sk, 0)
+            one_prime(P, pte, pa, sk2, 0)         # a repeated prime, another key, the counter where it stands
+            L.delete_parameters(C.byref(P))
+            return
+        # 2. the counter moves between primes: by a little (still inside prime 1's window) and by a lot
+        for bump in (1, 2, 10 ** 6):
+            pte, pa = init(seeds[0], seeds[3])
+            one_prime(P, pte, pa, sk, 0)
+            L.next_modulus(C.byref(P))
+            pa.counter += bump
+            for j in range(1, npr):
+                one_prime(P, pte, pa, sk, j)
+                if j + 1 < npr:
+                    L.next_modulus(C.byref(P))
+            rewind()
+        # 2b. the reference's bench order (device/bench/bench_sym.c:96-145 never rewinds the Parms between its
+        #     iterations): the init call finds the Parms at the LAST prime, the chain runs np-1, 0, 1, ...
+        for start in (npr - 1, 1):
+            rewind()
+            for _ in range(start):
+                L.next_modulus(C.byref(P))
+            pte, pa = init(seeds[2], seeds[0])
+            for k in range(npr):
+                one_prime(P, pte, pa, sk, (start + k) % npr)
+                L.next_modulus(C.byref(P))
+            rewind()
+        # 3. the plaintext, then the key, change between primes; a prime is repeated; gen_pk's form in between
+        pte, pa = init(seeds[1], seeds[3])
+        one_prime(P, pte, pa, sk, 0)
+        L.next_modulus(C.byref(P))
+        pte[5] += 12345
+        pte[n - 1] = -pte[n - 1] - 1
+        one_prime(P, pte, pa, sk, 1)
+        keep = int(pa.counter)
+        ep = rng.integers(-21, 22, n).astype(np.int8)
+        pk = _prng(seeds[2], 0)
+        one_prime(P, pte, pk, sk, 1, ep=ep)                   # ckks_sym.c:279-283: ep_small wins, own PRNG
+        assert pa.counter == keep
+        if npr > 2:
+            L.next_modulus(C.byref(P))
+            one_prime(P, pte, pa, sk2, 2)                     # another key from here on
+            back = _prng(seeds[1], keep)
+            one_prime(P, pte, back, sk2, 2)                   # the same prime again, same inputs
+            one_prime(P, pte, _prng(seeds[0], keep), sk2, 2)  # ... and under another seed
+        rewind()
+        L.delete_parameters(C.byref(P))
+
+    sequence()
+    monkeypatch.setenv("SE_AMD_LOWER_SPECULATION", "0")
+    sequence()

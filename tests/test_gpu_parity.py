@@ -1855,3 +1855,91 @@ def test_asym_chunked_pipeline_is_bit_identical(env):
         assert (host_u32(outs[0][0][b]) == r["c0"]).all() and (host_u32(outs[0][1][b]) == r["c1"]).all()
     ctx.close()
 
+
+
+_WATCHDOG_CHILD = r'''
+import os, sys, threading, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+import vectors as V
+dev = torch.device("cuda:0")
+state = {"what": "start", "t0": time.time()}
+def watchdog():
+    while True:
+        time.sleep(0.25)
+        if state["what"] is not None and time.time() - state["t0"] > float(sys.argv[2]):
+            print("WATCHDOG: no progress in", state["what"], flush=True)
+            os._exit(3)
+threading.Thread(target=watchdog, daemon=True).start()
+def step(what):
+    torch.cuda.synchronize()
+    state["what"], state["t0"] = what, time.time()
+def dt(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+rng = np.random.default_rng(5)
+# warm-up outside the watchdog window: library load, first context, kernel code upload
+state["what"] = None
+ctx = pkg.Context(1024, 1); ctx.close()
+for n, npr in ((1024, 1), (4096, 3)):
+    ctx = pkg.Context(n, npr)
+    sk = V.secret_key(n, seed=3)
+    ctx.set_secret_key(sk)
+    pk0, pk1 = ctx.gen_public_key(sk, bytes(range(64)), bytes(range(64, 128)))
+    ctx.set_public_key(pk0, pk1)
+    for B in (1, 2, 3, 7, 9, 65, 129):
+        seeds = dt(rng.integers(0, 256, (B, 64), dtype=np.uint8))
+        # k_sample_cbd: B * blocks not a multiple of 512; blocks_per_ct = 1 leaves ONE live lane in the only workgroup
+        for blocks in (1, 3, n // 16, 2 * (n // 16) + 1):
+            step("cbd n=%d B=%d blocks=%d" % (n, B, blocks))
+            out = torch.zeros((B, blocks * 16), dtype=torch.int8, device=dev)
+            ctx.sample_cbd(seeds, out, blocks)
+        # k_sample_ternary_window (+ redo): one ciphertext = a fraction of a workgroup
+        step("ternary n=%d B=%d" % (n, B))
+        codes = torch.zeros((B, n), dtype=torch.int8, device=dev)
+        ctx.sample_ternary(seeds, codes)
+        vals = dt(V.bench_values(B, n, first=11))
+        ss, sd = V.bench_seeds(B, first=11)
+        c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.zeros_like(c0)
+        # k_candidates through both staged dispatches (pair form: per-prime rows; lane form: window ranges), tiny
+        # capacities so that B * spec_cap is nowhere near a multiple of 512 and k_resolve_wave walks a flagged list
+        for flags, split in ((512, 1), (2048, 0)):
+            for cap in (None, 1, 7):
+                step("staged flags=%d n=%d B=%d cap=%s" % (flags, n, B, cap))
+                c2 = pkg.Context(n, npr); c2.set_secret_key(sk); c2.set_pipeline(1, split); c2.set_debug_flags(flags)
+                if cap is not None:
+                    c2.set_speculation_capacity(cap)
+                c2.encrypt_sym(vals, dt(ss), dt(sd), c0, c1)
+                torch.cuda.synchronize(); c2.close()
+        # the redo launches of the prime speculation (UniformArgs::only_from): windows of one guess force misses
+        step("spec redo n=%d B=%d" % (n, B))
+        c3 = pkg.Context(n, npr); c3.set_secret_key(sk); c3.set_debug_flags(256)
+        c3.encrypt_sym(vals, dt(ss), dt(sd), c0, c1); torch.cuda.synchronize(); c3.close()
+        step("asym n=%d B=%d" % (n, B))
+        ctx.encrypt_asym(vals, dt(sd), c0, c1)
+    step("close")
+    ctx.close()
+state["what"] = None
+print("WATCHDOG-OK", flush=True)
+'''
+
+
+def test_synchronised_kernels_do_not_hang_on_ragged_shapes(env, tmp_path):
+    """The phase-synchronised kernels (k_sample_cbd, k_candidates, k_sample_ternary_window: 96 workgroup barriers
+    per permutation) on the shapes where a barrier contract could break -- a last workgroup with ONE live lane, whole
+    waves past the end, B * blocks not a multiple of the workgroup size, candidate rows of 1 and 7, the masked redo
+    launches of the prime speculation -- run in a CHILD process under a watchdog: a launch that makes no progress for
+    5 s ends the child (exit code 3) instead of hanging the suite (a hang on the driver's box would cost the whole GPU
+    record).  Results are checked by the other tests; this one checks that every launch RETURNS."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "watchdog_child.py"
+    script.write_text(_WATCHDOG_CHILD)
+    try:
+        r = subprocess.run([sys.executable, str(script), root, "5"], capture_output=True, text=True, timeout=600,
+                           cwd=root)
+    except subprocess.TimeoutExpired as e:   # the child's own watchdog should have fired long before
+        pytest.fail("watchdog child did not end: " + str(e.stdout)[-500:])
+    assert r.returncode == 0 and "WATCHDOG-OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])

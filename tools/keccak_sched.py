@@ -473,10 +473,11 @@ __device__ __forceinline__ void keccak_null_sync()
 // the absorbed message, the last round only produces lanes 0..11.  {total} VALU instructions per permutation.
 //
 // CONTRACT: every wave of the workgroup that has not ended executes this block the same number of times (it contains
-// {4 * 24} workgroup barriers); launch the kernel with at least 2 waves per SIMD and workgroup (>= 512 threads).  Every
-// branch AROUND a call must be wave-uniform AND scalar for the compiler (`__any(...)`, `readfirstlane`): an exec-masked
-// region that a wave enters with an empty mask would still execute the barriers.  Lanes of a partially active wave may
-// be masked off (the wave runs the block once either way).
+// {4 * 24} workgroup barriers); launch the kernel with at least 2 waves per SIMD and workgroup (>= 512 threads).  A path
+// AROUND a call must be wave-uniform and must END the wave (`if (!__any(live)) return;`): a wave that went around the
+// block and lived on would meet the workgroup's later barriers out of step.  Lanes of a partially active wave may be
+// masked off, and a wave may even run the block with an empty mask (the barriers do not depend on exec): it runs the
+// block once either way.  tests/test_keccak_sync.py checks the compiled ISA of every caller for exactly this.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
