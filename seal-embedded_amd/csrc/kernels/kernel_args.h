@@ -120,6 +120,8 @@ hipError_t launch_uniform_bulk_pair(const DevParams &, const UniformArgs &, hipS
 hipError_t launch_uniform_candidates(const UniformArgs &, hipStream_t, uint32_t k_lo = 0, uint32_t k_cnt = 0xFFFFFFFFu);
 // staged-lane form: the bulk squeeze of one prime, ONE ciphertext per LANE (k_bulk_lane)
 hipError_t launch_uniform_bulk_lane(const DevParams &, const UniformArgs &, hipStream_t);
+// ... with TWO chain waves per SIMD kept in phase (k_bulk_lane_sync: keccak_f1600_sync), on half as many CUs
+hipError_t launch_uniform_bulk_lane_sync(const DevParams &, const UniformArgs &, hipStream_t);
 hipError_t launch_uniform_resolve(const DevParams &, const UniformArgs &, hipStream_t);
 // Small-batch prime speculation (se_context.cpp, encrypt_sym_small): the uniform sampler of prime
 // j >= 1 is run for every plausible start counter of a window at once ("virtual ciphertexts"), so

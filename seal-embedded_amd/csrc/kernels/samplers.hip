@@ -757,6 +757,110 @@ __global__ __launch_bounds__(512) void k_bulk_lane(DevParams P, UniformArgs A)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// PAIRED chains (round 5): k_bulk_lane with TWO chain waves per SIMD that stay in phase.  A lone chain wave issues one
+// instruction per ~4.4-5 cycles whatever its opcode; two waves of a SIMD that present the same
+// issue class at the same time share slots (v_xor 2.1, v_bitop3 2.8 cycles).  So the chains of a batch are packed two
+// per SIMD into 512-thread workgroups -- HALF as many CUs as one wave per SIMD would take, the other half of the chip
+// is left to the throughput kernels (candidates, CBD) -- and squeeze with the phase-synchronised FULL permutation of
+// keccak_sync.cuh (keccak_f1600_sync: state in / state out, 96 workgroup barriers).  Every live wave of a workgroup
+// runs the same number of permutations (FULL_STEPS + 1); waves without a ciphertext end before the first barrier.
+// Same outputs as k_bulk_lane (reject list, reject count, residues / markers).
+// ------------------------------------------------------------------------------------------
+// HOG: the kernel claims all 256 VGPRs a wave may have, so that two chain waves fill a SIMD's register file and no
+// other kernel's waves become resident beside them (throughput waves on the same SIMD take issue slots from the pair:
+// measured, the chain step stretches from ~13 to ~20 us).
+template <int LOGN, bool HOG>
+__global__ __launch_bounds__(512) void k_bulk_lane_sync(DevParams P, UniformArgs A)
+{
+    constexpr int N          = 1 << LOGN;
+    constexpr int FULL_STEPS = (N * 4) / 136;
+    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;
+    static_assert(TAIL_WORDS % 2 == 0 && TAIL_WORDS <= 32, "the tail fits one mask");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];   // reserved: one workgroup per CU
+    (void)pin_lds;
+    if constexpr (HOG) asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    if (A.debug_flags & 131072u) __builtin_amdgcn_s_setprio(3);   // A/B: the chain pair above every other wave of its SIMD
+    const size_t bq   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = bq < A.B;
+    if (A.flagged && bq == 0) A.flagged[0] = 0;   // read by this prime's k_resolve_wave
+    if (!__any(active)) return;                   // whole waves without a ciphertext END before the first barrier
+    const size_t b   = active ? bq : (size_t)A.B - 1;   // idle lanes shadow the last ciphertext, store nothing
+    const uint32_t j = A.prime_lo;
+    const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
+    uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
+    uint32_t *mylist = A.rej_list + b * A.rej_cap;
+    uint32_t s[50];   // lane i of the state = (s[2 i], s[2 i + 1])
+    {
+        uint32_t seed[16];
+        load_seed(seed, A.seeds, b);
+        KeccakState st;
+        prng_absorb(st, seed, A.ctr_in ? A.ctr_in[b] : 0);
+#pragma unroll
+        for (int i = 0; i < 25; i++) s[2 * i] = st.lo[i], s[2 * i + 1] = st.hi[i];
+    }
+    uint32_t nrej = 0;
+    auto word = [&](auto r4, uint32_t x, uint32_t &mask) -> uint32_t {
+        const bool rej   = x >= bound;
+        const uint32_t r = reduce_sample<decltype(r4)::value>(x, q, crh);
+        mask             = (mask << 1) | (rej ? 1u : 0u);
+        return rej ? kRejMarker : r;
+    };
+    const bool red4 = (uint64_t)bound <= 4ull * q;   // uniform per prime
+    auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
+        while (__any(mask != 0))
+        {
+            if (mask != 0)
+            {
+                const uint32_t p = (uint32_t)__clz((int)mask);
+                mask &= ~(0x80000000u >> p);
+                if (active && nrej < A.rej_cap) mylist[nrej] = first_pos + (p - (32u - count));
+                nrej++;
+            }
+        }
+    };
+    uint32_t idx = 0;
+    for (int step = 0; step < FULL_STEPS; step++)
+    {
+        keccak_f1600_sync(s, &kKeccakRC[0][0]);
+        uint32_t m0 = 0, m1 = 0;   // words 0..31 / 32..33 of this step
+        auto emit = [&](auto r4) {
+#pragma unroll
+            for (int i = 0; i < 17; i++)
+            {
+                uint32_t &mk = (i < 16) ? m0 : m1;
+                uint32_t w0  = word(r4, s[2 * i], mk);
+                uint32_t w1  = word(r4, s[2 * i + 1], mk);
+                if (active) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+            }
+        };
+        if (red4)
+            emit(std::true_type{});
+        else
+            emit(std::false_type{});
+        if (__any((m0 | m1) != 0))
+        {
+            flush(m0, 32, idx);
+            flush(m1, 2, idx + 32);
+        }
+        idx += 34;
+    }
+    if constexpr (TAIL_WORDS > 0)
+    {
+        keccak_f1600_sync(s, &kKeccakRC[0][0]);
+        uint32_t m0 = 0;
+#pragma unroll
+        for (int i = 0; i < TAIL_WORDS / 2; i++)
+        {
+            uint32_t w0 = word(std::false_type{}, s[2 * i], m0);
+            uint32_t w1 = word(std::false_type{}, s[2 * i + 1], m0);
+            if (active) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+        }
+        flush(m0, TAIL_WORDS, idx);
+    }
+    if (active) A.nrej[b] = nrej;
+}
+
 // candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4]; consecutive threads = consecutive k of one ciphertext.
 // Round 4: 512-thread workgroups and the phase-synchronised permutation, as k_sample_cbd (-DSEAMD_CBD_NOSYNC: round 3).
 // A launch covers candidates k_lo <= k < k_lo + k_cnt of every row of `stride` words (the staged-lane form fills a
@@ -1592,6 +1696,32 @@ hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st, uint3
     if (k_lo + k_cnt > stride) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A,
                        k_lo, k_cnt, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_uniform_bulk_lane_sync(const DevParams &P, const UniformArgs &A, hipStream_t st)
+{
+    if (A.B == 0) return hipSuccess;
+    if (!A.nrej || A.prime_hi != A.prime_lo + 1) return hipErrorInvalidValue;
+    // 8 waves per workgroup = two per SIMD; 84 KiB of reserved LDS: one workgroup per CU
+    const unsigned threads = 512, grid = (unsigned)(((size_t)A.B + threads - 1) / threads);
+    const size_t lds = 84 * 1024;
+#define SEAMD_LAUNCH_BULK_SYNC_H(L, H)                                                                                     \
+    (void)hipFuncSetAttribute((const void *)k_bulk_lane_sync<L, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_bulk_lane_sync<L, H>), dim3(grid), dim3(threads), lds, st, P, A)
+#define SEAMD_LAUNCH_BULK_SYNC(L) \
+    if (A.debug_flags & 65536u) { SEAMD_LAUNCH_BULK_SYNC_H(L, true); } else { SEAMD_LAUNCH_BULK_SYNC_H(L, false); }
+    switch (P.logn)
+    {
+        case 10: SEAMD_LAUNCH_BULK_SYNC(10); break;
+        case 11: SEAMD_LAUNCH_BULK_SYNC(11); break;
+        case 12: SEAMD_LAUNCH_BULK_SYNC(12); break;
+        case 13: SEAMD_LAUNCH_BULK_SYNC(13); break;
+        case 14: SEAMD_LAUNCH_BULK_SYNC(14); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef SEAMD_LAUNCH_BULK_SYNC
+#undef SEAMD_LAUNCH_BULK_SYNC_H
     return hipGetLastError();
 }
 

@@ -136,7 +136,7 @@ int Context::init(size_t n, size_t nprimes, int dev)
     // measured on one 256-CU MI355X and are scaled by the CU count; results are bit-identical either way)
     // (kept in members of their own: se_amd_set_debug_flags assigns the whole debug_flags field)
     if (const char *e = getenv("SE_AMD_STAGED")) staged_mode = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SE_AMD_STAGED_LANE")) staged_lane_mode = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("SE_AMD_STAGED_LANE")) staged_lane_mode = atoi(e);   // 0 off, 1 lone chains, 2 paired chains
     if (const char *e = getenv("SE_AMD_WINDOW_SIGMA")) window_sigma = atof(e);
     if (const char *e = getenv("SE_AMD_SPECULATION")) spec_mode = atoi(e) ? 1 : 0;
     dp         = to_dev_params(hp);
@@ -635,7 +635,7 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
     //   C : H_0 ► H_1 ► ... (counter ranges of the window; no dependency on the chains)
     //   A : cbd
     // debug_flags 2048 forces it, 8192 forbids it (A/B in one process)
-    const bool lane_staged = !split && overlap && (staged_lane_mode > 0 || (debug_flags & 2048)) &&
+    const bool lane_staged = !split && overlap && (staged_lane_mode > 0 || (debug_flags & (2048 | 32768))) &&
                              chain_waves_per_cu <= 8 && !(debug_flags & (1 | 2 | 4 | 8 | 16 | 32 | 64 | 8192));
     if (lane_staged)
     {
@@ -683,10 +683,15 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
                                0,             debug_flags,         nullptr, 0, 0, nullptr, d_nrej, ends[j], W,
                                d_flagged};
         };
+        // paired chains (debug flag 32768 / SE_AMD_STAGED_LANE=2): two chain waves per SIMD in phase on half the CUs
+        const bool paired = (staged_lane_mode == 2 || (debug_flags & 32768)) && B >= 512;
+        auto bulk = [&](const UniformArgs &ua) {
+            return paired ? launch_uniform_bulk_lane_sync(dp, ua, st) : launch_uniform_bulk_lane(dp, ua, st);
+        };
         // the chain workgroups first (one per CU, 84 KiB of LDS each): the throughput kernels fill in around them
         const size_t chain_ev = events.size();
         stage_begin(1, st);
-        SEAMD_HIP(launch_uniform_bulk_lane(dp, prime_args(0), st));
+        SEAMD_HIP(bulk(prime_args(0)));
         UniformArgs uw{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, 1, np,
                        d_win, spec_cap, 0, debug_flags, nullptr, 0, 0, nullptr, d_nrej, W, W};
         for (uint32_t j = 0; j < np; j++)
@@ -697,7 +702,8 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         }
         // the error sampler is needed last (by the fused kernel): it starts when the candidates the first resolves
         // wait for are done, beside the last range of the window
-        if (np >= 2 && !(debug_flags & 16384)) SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_cand[np - 2], 0));
+        // (paired chains leave half the chip to the throughput kernels: there the error sampler starts at once)
+        if (np >= 2 && !(debug_flags & 16384) && !paired) SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_cand[np - 2], 0));
         stage_begin(0, aux_stream);
         SEAMD_HIP(launch_sample_cbd(ca, aux_stream));
         stage_end(aux_stream);
@@ -705,7 +711,7 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         for (uint32_t j = 0; j < np; j++)
         {
             const UniformArgs ua = prime_args(j);
-            if (j) SEAMD_HIP(launch_uniform_bulk_lane(dp, ua, st));
+            if (j) SEAMD_HIP(bulk(ua));
             SEAMD_HIP(hipStreamWaitEvent(st, ev_cand[j], 0));
             SEAMD_HIP(launch_uniform_resolve(dp, ua, st));
         }

@@ -319,16 +319,20 @@ def test_staged_sampler_pipeline(env, shape, B):
         ctx.close()
 
 
+@pytest.mark.parametrize("flags", [2048, 32768], ids=["lone_chains", "paired_chains"])
 @pytest.mark.parametrize("shape,B", [((1024, 1), 70), ((4096, 3), 131), ((4096, 3), 1500), ((2048, 1), 513)],
                          ids=lambda v: str(v))
-def test_staged_lane_sampler_phase(env, shape, B):
+def test_staged_lane_sampler_phase(env, shape, B, flags):
     """The staged-LANE form of the symmetric sampler phase (round 5: k_bulk_lane -- one ciphertext per lane, only
     the bulk squeeze in the chain --, the redraw candidates of all primes as ONE window of the ciphertext's counter
     stream computed by the phase-synchronised k_candidates beside the chains, one light resolve per prime walking
     the window from the prime's start counter; forced with debug flag 2048 in front of the fused kernel) against the
     oracle: ragged batches (idle lanes, partial workgroups, a last candidate workgroup with few live lanes), a window
     that is far too short (every ciphertext finished by k_resolve_wave with candidates it computes itself), a reject
-    list that is too short (marker scan), repeated calls on the same scratch."""
+    list that is too short (marker scan), repeated calls on the same scratch.  Flag 32768: the chains as PAIRED waves
+    (k_bulk_lane_sync: two chain waves per SIMD squeezing with the phase-synchronised full permutation; B >= 512, else
+    the lone form serves the call) -- a last workgroup with a few live waves, whole waves that end before the first
+    barrier."""
     from oracle.pyoracle import Oracle
     torch = env["torch"]
     n, npr = shape
@@ -343,7 +347,7 @@ def test_staged_lane_sampler_phase(env, shape, B):
         ctx = env["pkg"].Context(n, npr)
         ctx.set_secret_key(sk)
         ctx.set_pipeline(1, 0)
-        ctx.set_debug_flags(2048)
+        ctx.set_debug_flags(flags)
         if spec_cap is not None:
             ctx.set_speculation_capacity(spec_cap)
         if rej_cap is not None:
@@ -1170,7 +1174,7 @@ def _compare_all_with_oracle(c0, c1, oracle_chunk, B, chunk=4096):
         del e1
 
 
-@pytest.mark.parametrize("form", ["dispatch", "lane_chain", "staged_lane"])
+@pytest.mark.parametrize("form", ["dispatch", "lane_chain", "staged_lane", "paired_chains"])
 def test_full_size_properties_config2(env, form):
     """(form: the sampler phase the library's dispatch picks at this batch; forced to the one-launch lane chain
     (debug flag 8192); forced to the staged-lane form of round 5 (2048) -- every ciphertext through each.)
@@ -1185,7 +1189,7 @@ def test_full_size_properties_config2(env, form):
     n, npr = 4096, 3
     B = int(os.environ.get("SE_TEST_FULL_B", "65536"))   # BASELINE config 2 batch
     ctx = env["pkg"].Context(n, npr)
-    ctx.set_debug_flags({"dispatch": 0, "lane_chain": 8192, "staged_lane": 2048}[form])
+    ctx.set_debug_flags({"dispatch": 0, "lane_chain": 8192, "staged_lane": 2048, "paired_chains": 32768}[form])
     sk = V.secret_key(n)
     ctx.set_secret_key(sk)
     o = Oracle(n, npr)

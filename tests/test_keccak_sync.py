@@ -106,6 +106,33 @@ def test_header_is_what_the_generator_writes():
     assert peak <= 120        # v8 .. : leaves a 128-VGPR kernel room for its own values
 
 
+def test_full_permutation_block_squeezes_shake256():
+    """keccak_f1600_sync (state in / state out, the squeeze step of the paired chain kernel k_bulk_lane_sync): absorb
+    seed || le64(ctr) || pad as keccak.cuh's prng_absorb does, run the block twice: the rate lanes after each run are
+    bytes [0, 136) and [136, 272) of SHAKE256(seed || le64(ctr)); 96 barriers per run."""
+    text = open(HEADER).read()
+    base = int(re.search(r"state pinned to v(\d+)\.\.", text).group(1))
+    lines = asm_of(text, "keccak_f1600_sync")
+    rng = np.random.default_rng(20261001)
+    for case in range(2):
+        seed = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+        ctr = [7, 2**63 + 99][case]
+        msg = seed + struct.pack("<Q", ctr)
+        block = bytearray(200)
+        block[:72] = msg
+        block[72] ^= 0x1F
+        block[135] ^= 0x80
+        st = list(struct.unpack("<50I", bytes(block)))
+        want = hashlib.shake_256(msg).digest(272)
+        regs = {base + k: st[k] for k in range(50)}
+        for run in range(2):
+            regs, barriers = run_asm(lines, regs)
+            assert barriers == 96
+            got = struct.pack("<34I", *[regs[base + k] for k in range(34)])
+            assert got == want[136 * run:136 * (run + 1)], (case, run)
+            regs = {base + k: regs[base + k] for k in range(50)}
+
+
 def test_generated_blocks_compute_shake256():
     text = open(HEADER).read()
     base = int(re.search(r"state pinned to v(\d+)\.\.", text).group(1))
@@ -145,7 +172,7 @@ def test_constraint_lists_cover_every_register_the_blocks_write():
     the clobber list; every register it READS before writing it is a pinned operand (or the table pointer); scc is
     clobbered; nothing outside v8..v77 / s16..s30 is touched."""
     text = open(HEADER).read()
-    for func in ("keccak_fresh96_sync", "keccak_fresh4_sync"):
+    for func in ("keccak_fresh96_sync", "keccak_fresh4_sync", "keccak_f1600_sync"):
         lines, outs, ins, clob = _asm_parts(text, func)
         pinned = {int(x) for x in re.findall(r"\"\+\{v(\d+)\}\"", outs)}          # in/out: readable from the start
         outonly = {int(x) for x in re.findall(r"\"=&\{v(\d+)\}\"", outs)}       # early-clobber outputs: write first

@@ -14,6 +14,8 @@ print('%-22s' % '$1', '$W', '%.3f ms' % d['ms_per_step'], '%.3f M/s' % (d['value
 for rep in $(seq $REPS); do
   run lane_chain 8192 ""
   run staged_lane_s3 2048 "SE_AMD_WINDOW_SIGMA=3"
-  run staged_lane_s4 2048 "SE_AMD_WINDOW_SIGMA=4"
-  run staged_lane_cbd_first $((2048+16384)) "SE_AMD_WINDOW_SIGMA=3"
+  run paired_chains 32768 "SE_AMD_WINDOW_SIGMA=3"
+  run paired_hog $((32768+65536)) "SE_AMD_WINDOW_SIGMA=3"
+  run paired_prio $((32768+131072)) "SE_AMD_WINDOW_SIGMA=3"
+  run paired_hog_prio $((32768+65536+131072)) "SE_AMD_WINDOW_SIGMA=3"
 done
