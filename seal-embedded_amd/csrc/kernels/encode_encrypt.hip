@@ -351,8 +351,8 @@ constexpr int enc_quad_stride()
 {
 #ifdef SEAMD_ASYM_SERIAL4
     return 20;
-#elif defined(SEAMD_SYM5)
-    return 28;   // the transpose region is aliased into the plane in that build: conflict-free rows fit
+#elif defined(SEAMD_SYM5) || defined(SEAMD_QALIAS28)
+    return 28;   // the transpose region is aliased into the plane in those builds: conflict-free rows fit
 #else
     return MODE == kModeAsym ? 28 : 20;
 #endif
@@ -423,7 +423,9 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     // trailing barrier; one workgroup barrier per prime keeps the next prime's first exchange off it): 51 KiB per
     // workgroup instead of 79, THREE workgroups per CU -- possible since the kernel needs 150 VGPRs (opaque_index
     // above; 206 before).  Fused stage 5.09 -> 4.83 ms per 65 536 (profiles/r04_ab_transform.log).
-#if defined(SEAMD_SYM5)
+#if defined(SEAMD_SYM5) || defined(SEAMD_QALIAS28)
+    // A/B builds: the symmetric / encode-only transpose region inside the NTT plane as well (28-word rows: conflict-free
+    // writes; one more workgroup barrier per prime), SEAMD_QALIAS28 = that alone, SEAMD_SYM5 = with half-plane exchanges
     constexpr bool QALIAS  = !GENERAL && LOGN <= 12 && (MODE != kModeAsym || ASYM3);
 #elif !defined(SEAMD_NO_ASYM3_ALIAS)
     constexpr bool QALIAS  = MODE == kModeAsym && ASYM3 && !GENERAL;
@@ -1075,6 +1077,8 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
 #if defined(SEAMD_SYM5)
         // half-plane encoder exchanges (sym / encode-only), transpose region aliased into the plane(s)
         shmem_fast = MODE == kModeAsym ? std::max(planes, std::max(ntt_planes, quads)) : std::max(ntt_planes, quads);
+#elif defined(SEAMD_QALIAS28)
+        shmem_fast = std::max(planes, std::max(ntt_planes, quads));
 #elif !defined(SEAMD_NO_ASYM3_ALIAS) && !defined(SEAMD_ASYM_SERIAL4)
         // public key: the transpose region is aliased into the three planes (encrypt_one, QALIAS); the serial A/B
         // build (SEAMD_ASYM_SERIAL4) has no alias and takes the plane + region sizing below
@@ -1082,7 +1086,8 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
 #else
         shmem_fast = std::max(planes, ntt_planes + quads);
 #endif
-        shmem_gen  = MODE == kModeAsym ? std::max(planes, ntt_planes) : shmem_fast;
+        // (general forms never alias the region: the A/B builds that alias it in the fast form size them separately)
+        shmem_gen  = MODE == kModeAsym ? std::max(planes, ntt_planes) : std::max(planes, ntt_planes + quads);
     }
     hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
