@@ -42,6 +42,9 @@ while time.time() - t0 < budget:
     ss = nr.integers(0, 256, (B, 64), dtype=np.uint8); sd = nr.integers(0, 256, (B, 64), dtype=np.uint8)
     ov, sp = rng.choice([(1, 2), (1, 2), (1, 1), (1, 0)])
     ctx.set_pipeline(ov, sp)
+    # (round 5) now and then the staged-lane sampler phase in front of the fused kernel: lone (2048) / paired (32768) chains
+    form = rng.choice([0, 0, 0, 2048, 32768])
+    ctx.set_debug_flags(form)
     c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.zeros_like(c0)
     st = torch.zeros(B, dtype=torch.uint8, device=dev)
     if mode == "sym":
@@ -53,7 +56,7 @@ while time.time() - t0 < budget:
     torch.cuda.synchronize()
     g0, g1 = c0.cpu().numpy().view(np.uint32), c1.cpu().numpy().view(np.uint32)
     if not (ok and bool(st.all()) and np.array_equal(g0, e0) and np.array_equal(g1, e1)):
-        print(f"MISMATCH seed={master} case={cases} n={n} np={npr} B={B} mode={mode} pipe=({ov},{sp}) case_seed={seed}", flush=True)
+        print(f"MISMATCH seed={master} case={cases} n={n} np={npr} B={B} mode={mode} pipe=({ov},{sp}) form={form} case_seed={seed}", flush=True)
         sys.exit(1)
     cases += 1; cts += B
     if cases % 5 == 0: print(f"{cases} cases, {cts} ciphertexts, {time.time()-t0:.0f}s", flush=True)
