@@ -13,5 +13,5 @@ cd /tmp && rm -rf /tmp/prof && ( timeout 1200 rocprofv3 --kernel-trace --stats -
 cd $GRAFT_REPO_ROOT; find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $O/prof/ \;
 for W in c2 c3 c4 c5; do PMC_WL=$W bash tools/gpu_run.sh pmc > $O/pmc_$W.log 2>&1; PMC_WL=$W bash tools/gpu_run.sh sq > $O/sq_$W.log 2>&1; done
 ls gpurun_out/pmc_c2 gpurun_out/sq_c2
-( timeout 800 FUZZ_SECONDS=600 python tools/fuzz_parity.py ) > $O/fuzz_parity.log 2>&1; tail -2 $O/fuzz_parity.log
-( timeout 500 FUZZ_SECONDS=400 python tools/fuzz_mid.py ) > $O/fuzz_mid.log 2>&1; tail -2 $O/fuzz_mid.log
+( timeout 800 env FUZZ_SECONDS=600 python tools/fuzz_parity.py ) > $O/fuzz_parity.log 2>&1; tail -2 $O/fuzz_parity.log
+( timeout 500 env FUZZ_SECONDS=400 python tools/fuzz_mid.py ) > $O/fuzz_mid.log 2>&1; tail -2 $O/fuzz_mid.log
