@@ -807,6 +807,12 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     const int t      = threadIdx.x;
     const size_t b   = blockIdx.x;
     const int np     = P.nprimes;
+#ifdef SEAMD_ABL_NTT_PAIR   // A/B build: j + 256 = primes j and j + 1 in ONE launch (the int32 row is read from HBM once)
+    const int jpair_first = j & 255, jpair_n = (j >> 8) + 1;
+    for (int jpair = 0; jpair < jpair_n; jpair++) { j = jpair_first + jpair; if (jpair) __syncthreads();
+    __asm__ volatile("" : "+s"(j));                 // nothing of one iteration's addressing is carried into the other
+    const int t = opaque_index((int)threadIdx.x);   // (shadows the kernel's t on purpose)
+#endif
     const uint32_t q = P.q[j], two_q = q << 1;
     uint32_t *poly   = A.c0 + (b * np + j) * N;
 
@@ -867,6 +873,9 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     {
         store_quads(poly, x, t);
     }
+#ifdef SEAMD_ABL_NTT_PAIR
+    }
+#endif
 }
 
 // Batched stand-alone forward NTT (ntt_inpl, ntt.c:168-189) of `count` polynomials mod q_j,

@@ -836,6 +836,21 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
             SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, st));
             stage_end(st);
         }
+#ifdef SEAMD_ABL_NTT_PAIR   // A/B build: two primes per k_ntt_fuse launch (N_{2k,2k+1} behind U_{2k+1}); np even
+        const bool pair_n = getenv("SE_AMD_NTT_PAIR") && np % 2 == 0;
+        if (pair_n)
+        {
+            if (j + 1 < np) SEAMD_HIP(hipEventRecord(ev_prime[j], st));   // the staged form's candidate stream waits on it too
+            if (j + 1 < np && (j & 1))
+            {
+                SEAMD_HIP(hipStreamWaitEvent(ax, ev_prime[j], 0));
+                stage_begin(5, ax);
+                SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)(j - 1) | 256, B, ax));
+                stage_end(ax);
+            }
+            continue;
+        }
+#endif
         if (j + 1 < np)
         {
             if (overlap)
@@ -854,6 +869,11 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
     }
     stage_begin(5, st);
+#ifdef SEAMD_ABL_NTT_PAIR
+    if (getenv("SE_AMD_NTT_PAIR") && np % 2 == 0)
+        SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)(np - 2) | 256, B, st));
+    else
+#endif
     SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)np - 1, B, st));
     stage_end(st);
     return 0;
