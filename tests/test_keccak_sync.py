@@ -307,3 +307,53 @@ def test_compiled_sync_kernels_keep_the_barrier_contract():
     for name in SYNC_KERNELS:
         m = re.search(r"\.amdhsa_kernel _ZN5seamd\d+" + name + r"E\w*\n(?:.*\n){0,6}?\s+\.amdhsa_private_segment_fixed_size (\d+)", meta)
         assert m and int(m.group(1)) == 0, (name, m and m.group(1))
+
+
+def test_compiled_paired_chain_kernel_keeps_the_barrier_contract():
+    """k_bulk_lane_sync (two chain waves per SIMD squeezing with keccak_f1600_sync; behind SE_AMD_STAGED_LANE=2): the
+    block sits in the step loop and once more for the tail words, so every live wave runs it FULL_STEPS + 1 times -- IF
+    the only way around a block is the whole-wave exit in front of the loop.  On the ISA of every instantiation:
+    exactly two asm regions with barriers (loop body, tail); a branch in front of the first that goes past it ends the
+    wave; between the two blocks control either stays in the loop or arrives right in front of the second block (the
+    loop exit) -- nothing jumps over the second block; behind the second block nothing branches back; no scratch."""
+    isa = _samplers_isa()
+    header = open(HEADER).read()
+    static = sum(1 for ln in _asm_parts(header, "keccak_f1600_sync")[0] if ln.strip() == "s_barrier")
+    branch_re = re.compile(r"\s+(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)")
+    starts = [i for i, ln in enumerate(isa) if re.match(r"^_ZN5seamd16k_bulk_lane_syncILi1[0-4]ELb[01]EE\w*:", ln)]
+    assert len(starts) == 10
+    for start in starts:
+        end = next(i for i in range(start, len(isa)) if isa[i].startswith(".Lfunc_end"))
+        body, name = isa[start:end], isa[start].split(":")[0]
+        app = [i for i, ln in enumerate(body) if ln.strip().startswith(";;#ASMSTART")]
+        noapp = [i for i, ln in enumerate(body) if ln.strip().startswith(";;#ASMEND")]
+        blocks = [(a, b) for a, b in zip(app, noapp) if any(ln.strip().startswith("s_barrier") for ln in body[a:b])]
+        assert len(blocks) == 2, (name, len(blocks))
+        for a, b in blocks:
+            assert sum(1 for ln in body[a:b] if ln.strip().startswith("s_barrier")) == static, name
+        (a1, b1), (a2, b2) = blocks
+        assert not any(ln.strip().startswith("s_barrier") for ln in body[:a1] + body[b1:a2] + body[b2:]), name
+        labels = {ln.split(":")[0]: i for i, ln in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", ln)}
+        endpgm = [i for i, ln in enumerate(body) if "s_endpgm" in ln]
+        assert len(endpgm) == 1, name
+        for i, ln in enumerate(body):
+            m = branch_re.match(ln)
+            if not m:
+                continue
+            tgt = labels[m.group(2)]
+            if i < a1:                                   # in front of the loop's block (the loop latch is laid out here)
+                if b1 <= tgt <= a2:
+                    continue                             # the loop exit: arrives in front of the tail block
+                if tgt > a1:
+                    j = tgt
+                    while "s_endpgm" not in body[j]:     # the whole-wave exit: straight to the end
+                        assert not branch_re.match(body[j]) and not body[j].strip().startswith("s_barrier"), (name, ln)
+                        j += 1
+                    assert tgt >= b2, (name, "jump into the loop past its block", ln.strip())
+            elif b1 <= i < a2:                           # loop body behind the block: stay in the loop or reach block 2
+                assert tgt <= a2, (name, "a path around the tail block", ln.strip())
+                assert not (a1 < tgt < b1), (name, "jump into the block", ln.strip())
+            elif i >= b2:                                # behind the tail block
+                assert tgt >= b2, (name, "branch back over a block", ln.strip())
+        text = "\n".join(body)
+        assert "scratch_" not in text, name
