@@ -753,7 +753,8 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
     # stage timers, the algorithmic bytes and PMC traffic of both.)
     by_name = {k["kernel"]: k for k in kernels}
     main = list(kernels)
-    if mode == "sym" and "k_sample_cbd" in by_name and "k_sample_uniform" in by_name:
+    # (only in the fused pipeline: in the per-prime pipeline the error sampler runs beside the FIRST chain launch only)
+    if mode == "sym" and "k_sample_cbd" in by_name and "k_sample_uniform" in by_name and "k_ntt_fuse" not in by_name:
         u, c = by_name["k_sample_uniform"], by_name["k_sample_cbd"]
         phase_ms = max(u["ms_per_step"], c["ms_per_step"])
         alg = u["algorithmic_bytes"] + c["algorithmic_bytes"]
