@@ -831,7 +831,11 @@ __global__ __launch_bounds__(512) void k_bulk_lane_sync(DevParams P, UniformArgs
                 uint32_t &mk = (i < 16) ? m0 : m1;
                 uint32_t w0  = word(r4, s[2 * i], mk);
                 uint32_t w1  = word(r4, s[2 * i + 1], mk);
+#ifdef SEAMD_ABL_PAIR_NOSTORE   // timing ablation (WRONG results): what the emit's store burst costs a chain pair
+                if (active && (w0 ^ w1) == 0x12345u) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+#else
                 if (active) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
+#endif
             }
         };
         if (red4)
