@@ -460,10 +460,15 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 #pragma unroll
             for (int e = 0; e < 16; e++)
             {
+#ifdef SEAMD_ABL_ASYM_NOBYTES   // timing ablation (WRONG results): what the 32 byte loads per prime and thread cost
+                uh[e] = (uint32_t)((tg + e + j) % 3) + q - 1u;
+                y[e]  = q + (uint32_t)((int32_t)((tg * 7 + e) & 15) - 8);
+#else
                 uint32_t code = (uint32_t)up[e << CTOP];
                 uh[e]         = code + q - 1u;            // q-1, q, q+1 == -1, 0, 1 (sample.c:98-111 mod q)
                 int32_t e1    = ep[e << CTOP];
                 y[e]          = q + (uint32_t)e1;          // == reduce_set_e_small (ckks_common.c:259-265) mod q
+#endif
             }
             reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
