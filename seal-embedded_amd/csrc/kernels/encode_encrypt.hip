@@ -23,7 +23,6 @@
 #include "../se_types.h"
 #include "kernel_args.h"
 #include "transform.cuh"
-#include "transform8.cuh"
 
 namespace seamd {
 
@@ -704,180 +703,6 @@ void k_encode_encrypt_general(DevParams P, DevTables T, EncArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
-// The fast fused kernel with EIGHT points per thread (n = 4096, symmetric / encode-only): 512 threads per
-// plaintext, radix-8 passes (transform8.cuh), at most 64 VGPRs -- 8 waves per SIMD where the 16-point form
-// runs 4 (VALU busy 79 % there, profiles/r05_sq_counters_c2.txt).  Same arithmetic per point, same outputs; a
-// plaintext that is not small goes to k_encode_encrypt_general through the same list.  LDS: the FP64 exchange
-// plane (36 KiB) covers the NTT plane (18 KiB) + the wave-local transpose region (16 KiB): 4 workgroups per CU.
-// ------------------------------------------------------------------------------------------
-#ifndef SEAMD_ENC8_WAVES
-#define SEAMD_ENC8_WAVES 8
-#endif
-
-__device__ __forceinline__ void load_quads8(uint32_t (&v)[8], const uint32_t *poly, int t)
-{
-    const uint32_t *base = poly + quad8_index(t, 0);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-    {
-        const uint4 w = *reinterpret_cast<const uint4 *>(base + (i << 8));
-        v[4 * i] = w.x, v[4 * i + 1] = w.y, v[4 * i + 2] = w.z, v[4 * i + 3] = w.w;
-    }
-}
-__device__ __forceinline__ void store_quads8(uint32_t *poly, const uint32_t (&v)[8], int t)
-{
-    uint32_t *base = poly + quad8_index(t, 0);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-        *reinterpret_cast<uint4 *>(base + (i << 8)) = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-}
-__device__ __forceinline__ void load_quads8_pairs(uint32_t (&w)[8], uint32_t (&wp)[8], const uint32_t *tab, int t)
-{
-    const uint32_t *base = tab + 2 * (size_t)quad8_index(t, 0);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-    {
-        const uint4 *p4 = reinterpret_cast<const uint4 *>(base + (i << 9));
-        const uint4 a = p4[0], b = p4[1];
-        w[4 * i] = a.x, wp[4 * i] = a.y, w[4 * i + 1] = a.z, wp[4 * i + 1] = a.w;
-        w[4 * i + 2] = b.x, wp[4 * i + 2] = b.y, w[4 * i + 3] = b.z, wp[4 * i + 3] = b.w;
-    }
-}
-
-// encode_plaintext (above) for the int32 fast form with 8 points per thread.  On return thread t owns the
-// plaintext coefficients k = t + (n/8) e, e = 0..7; `small` is workgroup-uniform.
-template <int LOGN>
-__device__ __forceinline__ void encode_plaintext8(const DevParams &P, const DevTables &T, const float *values,
-                                                  uint8_t *status, size_t b, unsigned char *smem, int32_t (&m)[8],
-                                                  bool &small)
-{
-    using G         = Xform8Geom<LOGN>;
-    constexpr int N = G::N;
-    const int t     = threadIdx.x;
-    double *plane   = reinterpret_cast<double *>(smem);
-    float *sv       = reinterpret_cast<float *>(smem);
-    static_assert(N / 8 == G::THREADS, "every thread stages one float4 piece");
-
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f nfacc = {0.0f, 0.0f};
-    {
-        const float4 v = reinterpret_cast<const float4 *>(values + b * (N / 2))[t];
-        nfacc          = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{0.0f, 0.0f}, nfacc);
-        nfacc          = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{0.0f, 0.0f}, nfacc);
-        sv[sv8_slot(4u * t, LOGN)]      = v.x;
-        sv[sv8_slot(4u * t + 1u, LOGN)] = v.y;
-        sv[sv8_slot(4u * t + 2u, LOGN)] = v.z;
-        sv[sv8_slot(4u * t + 3u, LOGN)] = v.w;
-    }
-    const float nfsum    = nfacc.x + nfacc.y;
-    const bool nonfinite = nfsum != nfsum;   // this thread staged a NaN or an infinity
-    __syncthreads();
-    double re[8], im[8];
-    {
-        const uint4 mp           = reinterpret_cast<const uint4 *>(T.gather_map8)[t];
-        const uint32_t packed[4] = {mp.x, mp.y, mp.z, mp.w};
-#pragma unroll
-        for (int e = 0; e < 8; e++)
-        {
-            const uint32_t idx = (packed[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
-            re[e]              = (double)sv[idx];
-            im[e]              = 0.0;
-        }
-    }
-    __syncthreads();
-    ifft8_tiles_real<LOGN>(re, im, T.ifft_w, plane, t);
-
-    double amax = 0.0;
-#pragma unroll
-    for (int e = 0; e < 8; e++)
-    {
-        re[e] = round_half_away(__dmul_rn(re[e], P.n_inv));
-        amax  = fmax(amax, fabs(re[e]));
-    }
-    small = __all(amax < P.small_bound && !nonfinite);
-#pragma unroll
-    for (int e = 0; e < 8; e++) m[e] = (int32_t)re[e];
-    const int wg = __ockl_wgred_or_i32(small ? 0 : kWgNotSmall);
-    small        = !(wg & kWgNotSmall);
-    if (status && t == 0 && small) status[b] = 1;   // small implies "no overflow"
-}
-
-template <int LOGN, int MODE>
-__global__ __launch_bounds__(Xform8Geom<LOGN>::THREADS, SEAMD_ENC8_WAVES)
-void k_encode_encrypt8(DevParams P, DevTables T, EncArgs A)
-{
-    static_assert(MODE == kModeSym || MODE == kModeEncodeOnly, "the public-key form keeps 16 points per thread");
-    using G            = Xform8Geom<LOGN>;
-    constexpr int N    = G::N;
-    constexpr int CTOP = G::CTOP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *qlds  = lds32 + G::SLOTS;   // transpose region behind the NTT plane
-    const int t     = threadIdx.x;
-    const size_t b  = blockIdx.x;
-    const int np    = P.nprimes;
-
-    int32_t m[8];
-    bool small;
-    encode_plaintext8<LOGN>(P, T, A.values, A.status, b, smem, m, small);
-    if (!small)
-    {
-        if (t == 0) A.general[1 + atomicAdd(A.general, 1u)] = (uint32_t)b;
-        return;
-    }
-    if constexpr (MODE == kModeSym)
-    {
-#pragma unroll
-        for (int e = 0; e < 8; e++) m[e] += A.err[b * N + (e << CTOP) + t];
-    }
-    if (A.pte)
-    {
-#pragma unroll
-        for (int e = 0; e < 8; e++) A.pte[b * N + (e << CTOP) + t] = m[e];
-    }
-    if constexpr (MODE == kModeEncodeOnly)
-    {
-        if (!A.c0) return;
-    }
-    for (int j = 0; j < np; j++)
-    {
-        const uint32_t q = P.q[j], two_q = q << 1;
-        const uint32_t *RW = T.ntt_rw + 2 * xform_table_len(N) * j;
-        const size_t pb    = (b * np + j) * N;
-        const int tg       = MODE == kModeEncodeOnly ? t : opaque_index(t);
-        uint32_t x[8], a[8];
-        if constexpr (MODE == kModeSym) load_quads8(a, A.c1 + pb, tg);   // a_j from HBM: lands while the NTT runs
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = (uint32_t)m[e] + two_q;   // representative in (0, 4q), modarith.cuh
-        ntt8_tiles<LOGN>(x, RW, q, lds32, t);
-        if constexpr (MODE != kModeSym)
-        {
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = canon4(x[e], q, two_q);
-        }
-        tile8_to_quads(x, qlds, t);
-        if (A.ntt_pte)
-        {
-            uint32_t cx[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) cx[e] = canon4(x[e], q, two_q);
-            store_quads8(A.ntt_pte + pb, cx, tg);
-        }
-        if constexpr (MODE == kModeSym)
-        {
-            // c0 = -(s_hat . a) + NTT(m + e)   (ckks_sym.c:273-300); a was written to c1
-            uint32_t w[8], wp[8], out[8];
-            load_quads8_pairs(w, wp, T.s_hat + (size_t)2 * N * j, tg);
-#pragma unroll
-            for (int e = 0; e < 8; e++) out[e] = sub_mul_canon(x[e], a[e], w[e], wp[e], q, two_q);
-            store_quads8(A.c0 + pb, out, tg);
-        }
-        else
-            store_quads8(A.c0 + pb, x, tg);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Split form of the symmetric path, used so that everything that does not need `a` overlaps with
 // the (long, one-wave-per-SIMD) uniform sampler:
 //   k_encode_rns : encode -> + e -> per prime signed reduction, residues stored (natural order)
@@ -1280,29 +1105,10 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
     }
     hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    bool launched = false;
-    if constexpr (LOGN == 12 && MODE != kModeAsym)
-    {
-        if (A.form == 1)
-        {
-            using G8           = Xform8Geom<LOGN>;
-            const size_t shmem = (size_t)G8::SLOTS * sizeof(double);
-            static_assert((size_t)G8::SLOTS * sizeof(uint32_t) + (size_t)G8::THREADS * 8 * sizeof(uint32_t) <=
-                              (size_t)G8::SLOTS * sizeof(double),
-                          "NTT plane + transpose region fit inside the encoder's plane");
-            (void)hipFuncSetAttribute((const void *)k_encode_encrypt8<LOGN, MODE>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            hipLaunchKernelGGL((k_encode_encrypt8<LOGN, MODE>), dim3((unsigned)B), dim3(G8::THREADS), shmem, st, P, T, A);
-            launched = true;
-        }
-    }
-    if (!launched)
-    {
-        (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, MODE>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast);
-        hipLaunchKernelGGL((k_encode_encrypt<LOGN, MODE>), dim3((unsigned)B), dim3(G::THREADS), shmem_fast, st, P, T,
-                           A);
-    }
+    (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, MODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast);
+    hipLaunchKernelGGL((k_encode_encrypt<LOGN, MODE>), dim3((unsigned)B), dim3(G::THREADS), shmem_fast, st, P, T,
+                       A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the plaintexts the fast form declined (normally none: the workgroups read a zero count and leave)

@@ -33,8 +33,6 @@ struct EncArgs
     uint8_t *compact;    // split kernels only (optional): [B] k_encode_rns -> k_ntt_fuse, 1 = the plaintext
                          // was small and travels as ONE int32 row (in c0's last prime row) instead of np
                          // residue rows
-    uint32_t form;       // fused kernel, n = 4096 symmetric / encode-only: 1 = the 8-points-per-thread form
-                         // (k_encode_encrypt8), 0 = 16 points per thread
 };
 struct UniformArgs
 {

@@ -139,7 +139,6 @@ int Context::init(size_t n, size_t nprimes, int dev)
     if (const char *e = getenv("SE_AMD_STAGED_LANE")) staged_lane_mode = atoi(e);   // 0 off, 1 lone chains, 2 paired chains
     if (const char *e = getenv("SE_AMD_WINDOW_SIGMA")) window_sigma = atof(e);
     if (const char *e = getenv("SE_AMD_SPECULATION")) spec_mode = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SE_AMD_TRANSFORM8")) transform8_mode = atoi(e) ? 1 : 0;
     dp         = to_dev_params(hp);
     dp.num_cus = (uint32_t)num_cus;
     rej_cap = (uint32_t)(n / 16 > 256 ? n / 16 : 256);
@@ -167,15 +166,6 @@ int Context::init(size_t n, size_t nprimes, int dev)
                 {
                     const size_t src = (n >> (b + 1)) + (t << (3 - b)) + g;
                     const size_t dst = n + ((8u >> b) - 1 + g) * th + t;
-                    tab[2 * dst] = tab[2 * src], tab[2 * dst + 1] = tab[2 * src + 1];
-                }
-        // ... and the 8-points-per-thread form's (transform8.cuh, root8_index)
-        for (int b = 0; b < 3; b++)
-            for (size_t g = 0; g < ((size_t)4 >> b); g++)
-                for (size_t t = 0; t < n / 8; t++)
-                {
-                    const size_t src = (n >> (b + 1)) + (t << (2 - b)) + g;
-                    const size_t dst = xform8_offset(n) + ((4u >> b) - 1 + g) * (n / 8) + t;
                     tab[2 * dst] = tab[2 * src], tab[2 * dst + 1] = tab[2 * src + 1];
                 }
     };
@@ -222,20 +212,17 @@ int Context::init(size_t n, size_t nprimes, int dev)
         dt.index_map = d_map;
     }
     {
-        std::vector<uint16_t> gather(2 * n);
+        std::vector<uint16_t> gather(n);
         // point k = 16 t + e is entry e % 8 of the uint4 at [e / 8][t]
         for (size_t k = 0; k < n; k++)
         {
             const size_t t = k >> 4, e = k & 15;
             gather[((e >> 3) * (n / 16) + t) * 8 + (e & 7)] =
                 (uint16_t)sv_slot((uint32_t)(inv[k] & (n / 2 - 1)), (uint32_t)hp.logn);
-            // 8-point form: point k = 8 t + e is entry e of the uint4 at [t], staging layout sv8_slot
-            gather[n + k] = (uint16_t)sv8_slot((uint32_t)(inv[k] & (n / 2 - 1)), (uint32_t)hp.logn);
         }
-        SEAMD_HIP(hipMalloc((void **)&d_gather, 2 * n * sizeof(uint16_t)));
-        SEAMD_HIP(hipMemcpy(d_gather, gather.data(), 2 * n * sizeof(uint16_t), hipMemcpyHostToDevice));
-        dt.gather_map  = d_gather;
-        dt.gather_map8 = d_gather + n;
+        SEAMD_HIP(hipMalloc((void **)&d_gather, n * sizeof(uint16_t)));
+        SEAMD_HIP(hipMemcpy(d_gather, gather.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+        dt.gather_map = d_gather;
     }
     dt.inv_map = d_inv_map;
     dt.ifft_w  = d_ifft_w;
@@ -732,7 +719,6 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         if (profiling && chain_ev < events.size()) (void)hipEventRecord(events[chain_ev].stop, st);
         SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
         stage_begin(3, st);
-        ea.form = enc_form();
         SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
         stage_end(st);
         return 0;
@@ -757,7 +743,6 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         stage_end(st);
         if (overlap) SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
         stage_begin(3, st);
-        ea.form = enc_form();
         SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
         stage_end(st);
         return 0;
@@ -1128,7 +1113,6 @@ int Context::encode_ntt(const float *d_values, size_t B, uint32_t *d_out, int64_
     {
         EncArgs ea{d_values, nullptr, nullptr, d_out, nullptr, nullptr, d_pte, d_status, d_general};
         stage_begin(3, st);
-        ea.form = enc_form();
         hipError_t e = launch_encode_encrypt(dp, dt, ea, kModeEncodeOnly, B, st);
         if (e != hipSuccess) rc = hip_fail(e, "launch_encode_encrypt");
         stage_end(st);

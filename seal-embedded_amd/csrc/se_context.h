@@ -104,16 +104,6 @@ struct Context
     int staged_mode = -1;  // pair-form staged sampler of the per-prime pipeline: -1 = by batch size, 0 never, 1 always (SE_AMD_STAGED)
     int staged_lane_mode = 0;   // staged-lane sampler phase in front of the fused kernel (SE_AMD_STAGED_LANE; debug_flags 2048 / 8192)
     double window_sigma = 3.0;  // its candidate window: mean + this many sigma of the cumulative draw count (SE_AMD_WINDOW_SIGMA)
-    // fused symmetric / encode-only kernel at n = 4096: 8 points per thread, 512 threads per plaintext (kernels/
-    // transform8.cuh) instead of 16 / 256: -1 = the measured default (enc_form), 0 never, 1 always (SE_AMD_TRANSFORM8;
-    // debug_flags 1 << 18 force / 1 << 19 forbid for A/B runs in one process)
-    int transform8_mode = -1;
-    uint32_t enc_form() const
-    {
-        if (hp.logn != 12 || (debug_flags & (1u << 19))) return 0;
-        if (debug_flags & (1u << 18)) return 1;
-        return transform8_mode == 1 ? 1u : 0u;
-    }
     bool overlap = true;   // run independent kernels on the auxiliary stream
     int split_mode = 2;    // symmetric path: 0 = fused kernel, 1 = per-prime software pipeline
                            // (encode_rns + uniform_j || ntt_fuse_{j-1}), 2 = choose per call: the split

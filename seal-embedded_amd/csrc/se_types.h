@@ -32,10 +32,9 @@ struct DevTables
 {
     const uint16_t *inv_map;   // [n]   x[k] <- values[inv_map[k] & (n/2-1)]
     const double *ifft_w;      // [n][2] (re, im) of W[t], t = h + j  (fft.c:129), then the thread-major copy of
-                               // the window-0 entries [15][n/16][2] and of the 8-point form's [7][n/8][2]
-                               // (xform_table_len)
+                               // the window-0 entries [15][n/16][2] (xform_table_len)
     const uint32_t *ntt_rw;    // [np][ (-root mod 2^32, shoup(root)) indexed h + g (ntt.c:40-52): [n][2], then the
-                               // thread-major copies of the window-0 entries [15][n/16][2], [7][n/8][2] ]
+                               // thread-major copy of the window-0 entries [15][n/16][2] ]
     const uint32_t *s_hat;     // [np][n][2] (NTT(s), shoup)       sym
     const uint32_t *pk0;       // [np][n][2] (pk0, shoup)          asym
     const uint32_t *pk1;       // [np][n][2] (pk1, shoup)          asym
@@ -43,8 +42,6 @@ struct DevTables
     const uint16_t *index_map; // [n] forward index map (decode slot pick)
     const uint16_t *gather_map; // encoder gather: LDS position (sv_slot) of the value that feeds point 16 t + e,
                                 // stored [e / 8][t][e % 8] (one uint4 per thread and half)
-    const uint16_t *gather_map8; // 8-point form: LDS position (sv8_slot) of the value that feeds point 8 t + e,
-                                 // stored [t][e] (one uint4 per thread)
 };
 
 // Root tables carry a second, thread-major copy of the entries a pass over window 0 reads (transform.cuh:
@@ -52,16 +49,9 @@ struct DevTables
 // CONSECUTIVE entries per lane -- 64 different cache lines per wave load).  Row e = (8 >> b) - 1 + g of the
 // copy holds that entry for t = 0 .. n/16-1, so a wave load reads 64 consecutive entries.
 // Elements (pairs) of one table: n natural + 15 n/16 transposed.
-// The 8-points-per-thread transforms (transform8.cuh) read a thread-major copy of their own for window 0: stages
-// b = 2..0 need 1 / 2 / 4 consecutive entries per lane; row (4 >> b) - 1 + g holds the entry of group g for
-// t = 0 .. n/8-1.  It sits behind the 16-point copy: 7 n/8 more pairs.
-constexpr size_t xform8_offset(size_t n)
-{
-    return n + 15 * (n / 16);
-}
 constexpr size_t xform_table_len(size_t n)
 {
-    return xform8_offset(n) + 7 * (n / 8);
+    return n + 15 * (n / 16);
 }
 
 // LDS position of values[i] in the encoder's staging array.  Thread t gathers, for each e, the value
@@ -75,14 +65,6 @@ constexpr uint32_t sv_slot(uint32_t i, uint32_t logn)
     return ((i >> s) & 31u) | ((i & ((1u << s) - 1u)) << 5) | ((i >> (s + 5)) << (s + 5));
 }
 
-// The same for the 8-points-per-thread encoder (thread t gathers the values feeding points 8t + e): the lanes step
-// the argument twice as finely, one more bit of rotation puts h into the bank bits (tools/lds_conflicts.py:
-// 0 conflict cycles at n = 4096 against 128 with sv_slot's rotation).
-constexpr uint32_t sv8_slot(uint32_t i, uint32_t logn)
-{
-    const uint32_t s = logn - 9;
-    return ((i >> s) & 31u) | ((i & ((1u << s) - 1u)) << 5) | ((i >> (s + 5)) << (s + 5));
-}
 
 enum Mode : int
 {
