@@ -809,15 +809,21 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
         # continuity with earlier rounds' lines, under names that do not say "frac": issue_estimate_4cyc*.
         est4 = floor_ms / ms_per_step
         est4_clk = (floor_ms * VALU_CLOCK_HZ / (clock["mean_mhz"] * 1e6) / ms_per_step) if clock else None
-        headline = None
+        # (`frac` is always a number when the SQ counters are there -- without a matching valu_mix.json it
+        # falls back to the 4-cycle estimate and `frac_is` says so; `schema` names this meaning of the field)
         if weighted:
             headline = weighted["frac_at_sampled_clock"] if weighted["frac_at_sampled_clock"] is not None \
                 else weighted["frac"]
+        else:
+            headline = est4_clk if est4_clk is not None else est4
         valu = {"bound": "valu", "wave_insts_per_step": insts, "simds": simds, "clock_hz": VALU_CLOCK_HZ,
                 "sampled_clock_mhz": clock["mean_mhz"] if clock else None,
                 "frac": headline,
+                "schema": "r5: frac = opcode-weighted issue bound (rounds 1-4: the 4-cycle estimate)",
                 "frac_is": ("opcode-weighted issue bound / step time at the sampled clock" if weighted and clock else
-                            "opcode-weighted issue bound / step time at the nominal clock" if weighted else None),
+                            "opcode-weighted issue bound / step time at the nominal clock" if weighted else
+                            "FALLBACK: 4-cycle issue estimate / step time (profiles/valu_mix.json was built for other "
+                            "kernel sources, no opcode-weighted bound) -- an estimate that can exceed 1.0, not a bound"),
                 "floor_ms_weighted": weighted["floor_ms"] if weighted else None,
                 "frac_weighted": weighted["frac"] if weighted else None,
                 "floor_ms_weighted_at_sampled_clock": weighted["floor_ms_at_sampled_clock"] if weighted else None,
@@ -948,6 +954,25 @@ def run_config(be, coll, name, B, steps, warmup, rank, world, want_cpu, cpu_budg
     return res
 
 
+def configs_summary(names, results):
+    """The further configurations in < 500 bytes, as the LAST key of the line: the driver keeps the tail of stdout
+    verbatim and drops keys it does not know from its parsed copy, so this is what makes C3 / C4 / C5 / C1 visible in
+    its record beside its own clock around the run.  Per workload: value (units/s), ms_per_step,
+    frac (whole-step HBM fraction), dominant_ms (longest critical-path kernel entry)."""
+    def sig(x):
+        return float("%.4g" % x) if isinstance(x, (int, float)) else None
+    out = {}
+    for w, r in zip(names, results):
+        if "error" in r and "value" not in r:
+            out[w] = {"error": str(r["error"])[:40]}
+            continue
+        roof = r.get("roofline") or {}
+        dom = roof.get("dominant_kernel") or {}
+        out[w] = {"value": sig(r.get("value")), "ms_per_step": sig(r.get("ms_per_step")), "frac": sig(roof.get("frac")),
+                  "dominant_ms": sig(dom.get("ms_per_step"))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1013,6 +1038,8 @@ def main():
             r = {"config": {"workload": DESCR[w]}, "error": repr(e)}
         extra.append(r)
         line["other_configs"] = extra
+        line.pop("other_configs_summary", None)
+        line["other_configs_summary"] = configs_summary(others[:len(extra)], extra)   # stays the LAST key
         deadline.update(line)
     if rank == 0:
         print(json.dumps(line), flush=True)

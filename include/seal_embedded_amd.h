@@ -363,11 +363,9 @@ int se_amd_reserve(se_amd_ctx *ctx, size_t B);
  * uniform sampler that make outputs WRONG (tools/ablate.py).  Every other bit only selects among bit-identical forms:
  *   8 no helper waves, 16 helper waves without speculation, 32 / 64 force the lane / wave form of the chain kernels,
  *   128 early encoder at n = 16384, 256 speculation windows of one guess (forces the miss path), 512 / 1024 force /
- *   forbid the pair-form staged sampler, 2048 / 8192 force / forbid the staged-lane sampler phase in front of the
- *   fused kernel, 32768 the same with paired chains (+ 65536 register hog, 131072 chain priority), 16384 its error
- *   sampler first, 4096 ternary window of blocks + 2 counters (forces the fallback).
- * The environment overrides SE_AMD_STAGED, SE_AMD_STAGED_LANE, SE_AMD_SPECULATION, SE_AMD_WINDOW_SIGMA
- * are read at context creation into members of their own and survive this call. */
+ *   forbid the pair-form staged sampler, 4096 ternary window of blocks + 2 counters (forces the fallback).
+ * The environment overrides SE_AMD_STAGED, SE_AMD_SPECULATION are read at context creation into
+ * members of their own and survive this call. */
 int se_amd_set_debug_flags(se_amd_ctx *ctx, uint32_t flags);
 /* pipeline shape of the symmetric path (A/B experiments): overlap = use the auxiliary stream,
  * split = 0 fused kernel, 1 per-prime software pipeline, 2 choose per call (default 1, 2). */

@@ -26,18 +26,6 @@
 
 namespace seamd {
 
-// Synchronisation diet of the transforms (transform.cuh, RedealSync: wave-local first / last exchange, leading
-// barriers): built under -DSEAMD_FAST_SYNC.  Measured neutral on every workload (10 of 24 workgroup barriers
-// per plaintext gone, C5 31.47 / 31.75 ms against 31.47 / 31.53 ms, profiles/r03_ab_sync_shuffle.log) -- the
-// barriers are not what the transform kernels wait for -- so the default stays the simpler form (every
-// exchange: write, barrier, read, barrier).
-#ifdef SEAMD_FAST_SYNC
-constexpr bool kFastSync = true;
-#else
-constexpr bool kFastSync = false;
-#endif
-
-
 __device__ __forceinline__ void load16(uint32_t (&v)[16], const uint32_t *p)
 {
     const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
@@ -257,29 +245,16 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
     }
     __syncthreads();
 
-    // inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183)
-    // kFastSync (transform.cuh, RedealSync): the first exchange is wave-local, the others lead with their
-    // barrier.  The barrier above separates the gather's reads from it; the workgroup reduction below is the
-    // barrier behind it.
-    auto plain_ifft = [&]() {
-#ifdef SEAMD_NO_REAL_PASS0
-        ifft_tiles<LOGN, false, false, kFastSync>(re, im, T.ifft_w, plane, t);
-#elif defined(SEAMD_SYM5)
-        // A/B: the fast fused forms at FIVE workgroups per CU -- exchanges through a 17 KiB half plane
-        ifft_tiles<LOGN, true, false, false, (sizeof(MT) == 4 && LOGN <= 12)>(re, im, T.ifft_w, plane, t);
-#else
-        ifft_tiles<LOGN, true, false, kFastSync>(re, im, T.ifft_w, plane, t);  // real input: short butterflies in pass 0
-#endif
-    };
+    // inverse FFT (no 1/n: folded into n_inv, ckks_common.c:183); real input: short butterflies in pass 0
     if constexpr (BRANCH_EXACT)
     {
         if (wg_nonfinite)
-            ifft_tiles<LOGN, false, true, kFastSync>(re, im, T.ifft_w, plane, t);
+            ifft_tiles<LOGN, false, true>(re, im, T.ifft_w, plane, t);
         else
-            plain_ifft();
+            ifft_tiles<LOGN, true>(re, im, T.ifft_w, plane, t);
     }
     else
-        plain_ifft();
+        ifft_tiles<LOGN, true>(re, im, T.ifft_w, plane, t);
 
     // round to int64, overflow check (ckks_common.c:183-206).  The largest magnitude of the thread
     // serves both the overflow test and the wave-uniform "small" flag: when every coefficient of
@@ -349,13 +324,7 @@ __device__ __forceinline__ void encode_plaintext(const DevParams &P, const DevTa
 template <int MODE>
 constexpr int enc_quad_stride()
 {
-#ifdef SEAMD_ASYM_SERIAL4
-    return 20;
-#elif defined(SEAMD_SYM5) || defined(SEAMD_QALIAS28)
-    return 28;   // the transpose region is aliased into the plane in those builds: conflict-free rows fit
-#else
     return MODE == kModeAsym ? 28 : 20;
-#endif
 }
 
 template <int LOGN, int MODE, bool GENERAL>
@@ -364,11 +333,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 {
     const int t = thread_index<GENERAL>();
     using G            = XformGeom<LOGN>;
-#ifdef SEAMD_ASYM_SERIAL4
-    constexpr bool ASYM3 = false;       // A/B: one NTT at a time, one plane + transpose region, 4 workgroups per CU
-#else
     constexpr bool ASYM3 = LOGN <= 12;  // three-way NTT per prime (three LDS planes; spills at n = 8192)
-#endif
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
@@ -422,16 +387,9 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     // The public-key form's transpose region lives INSIDE its three planes (free after the last exchange's
     // trailing barrier; one workgroup barrier per prime keeps the next prime's first exchange off it): 51 KiB per
     // workgroup instead of 79, THREE workgroups per CU -- possible since the kernel needs 150 VGPRs (opaque_index
-    // above; 206 before).  Fused stage 5.09 -> 4.83 ms per 65 536 (profiles/r04_ab_transform.log).
-#if defined(SEAMD_SYM5) || defined(SEAMD_QALIAS28)
-    // A/B builds: the symmetric / encode-only transpose region inside the NTT plane as well (28-word rows: conflict-free
-    // writes; one more workgroup barrier per prime), SEAMD_QALIAS28 = that alone, SEAMD_SYM5 = with half-plane exchanges
-    constexpr bool QALIAS  = !GENERAL && LOGN <= 12 && (MODE != kModeAsym || ASYM3);
-#elif !defined(SEAMD_NO_ASYM3_ALIAS)
+    // above; 206 before).  Fused stage 5.09 -> 4.83 ms per 65 536 (profiles/r04_ab_transform.log).  (The same alias
+    // for the symmetric / encode-only forms, 28-word rows: no gain, profiles/r05_ab_qalias28.log.)
     constexpr bool QALIAS  = MODE == kModeAsym && ASYM3 && !GENERAL;
-#else
-    constexpr bool QALIAS  = false;
-#endif
     uint32_t *qlds         = lds32 + (QALIAS ? 0 : (MODE == kModeAsym && ASYM3 ? 3 : 1)) * G::SLOTS;
     auto to_quads = [&](uint32_t (&v)[16]) {
         if constexpr (QUADS) tile_to_quads<QSTRIDE>(v, qlds, t);
@@ -460,15 +418,10 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 #pragma unroll
             for (int e = 0; e < 16; e++)
             {
-#ifdef SEAMD_ABL_ASYM_NOBYTES   // timing ablation (WRONG results): what the 32 byte loads per prime and thread cost
-                uh[e] = (uint32_t)((tg + e + j) % 3) + q - 1u;
-                y[e]  = q + (uint32_t)((int32_t)((tg * 7 + e) & 15) - 8);
-#else
                 uint32_t code = (uint32_t)up[e << CTOP];
                 uh[e]         = code + q - 1u;            // q-1, q, q+1 == -1, 0, 1 (sample.c:98-111 mod q)
                 int32_t e1    = ep[e << CTOP];
                 y[e]          = q + (uint32_t)e1;          // == reduce_set_e_small (ckks_common.c:259-265) mod q
-#endif
             }
             reduce_signed16(m, x, q, crh, crl, small);
             ntt_tiles3<LOGN>(uh, y, x, RW, q, lds32, t);
@@ -503,7 +456,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
         }
         else if constexpr (MODE == kModeAsym)
         {
-            // one transform at a time (n >= 8192; n <= 4096 under SEAMD_ASYM_SERIAL4: quad-layout epilogues)
+            // one transform at a time (n >= 8192)
             // u_hat = NTT(expand(u))   (ckks_asym.c:235-241; code 0 -> q-1, 1 -> 0, 2 -> 1)
             uint32_t uh[16];
             const int8_t *up = A.ucodes + b * N + tg;
@@ -584,27 +537,14 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
         }
         else
         {
-#ifndef SEAMD_NO_PREFETCH_A
             // a_j comes from HBM: requested before the transform, it lands while the NTT runs (fused stage
             // 2.60 -> 2.38 ms per 65 536, profiles/r04_ab_transform.log; 16 VGPRs the NTT phase has to spare)
             uint32_t a_pre[16];
             if constexpr (MODE == kModeSym && QUADS) ld_poly<QUADS>(a_pre, A.c1 + pb, tg);
-#endif
-#ifdef SEAMD_PREFETCH_PAIRS
-            // A/B: the (s_hat, shoup) pairs requested here as well (L2-resident; in the default form their round
-            // trip sits between the transform and the epilogue: 8 loads, then s_waitcnt 25 instructions later)
-            uint32_t w_pre[16], wp_pre[16];
-            if constexpr (MODE == kModeSym && QUADS) ld_pairs<QUADS>(w_pre, wp_pre, T.s_hat + kb, tg);
-#endif
             // NTT(m + e mod q_j)   (ckks_sym.c:286-292)
             reduce_signed16(m, x, q, crh, crl, small);  // see modarith.cuh: the fused
                                                                           // symmetric kernel keeps the exact form
-            // the last exchange of the NTT runs wave-locally in the wave's chunk of the transpose region
-            // (which to_quads reuses right after: same wave, program order)
-            if constexpr (QUADS && kFastSync)
-                ntt_tiles<LOGN, 64 * QSTRIDE>(x, RW, q, lds32, t, qlds);
-            else
-                ntt_tiles<LOGN>(x, RW, q, lds32, t);
+            ntt_tiles<LOGN>(x, RW, q, lds32, t);
             if constexpr (MODE != kModeSym)
             {
 #pragma unroll
@@ -622,31 +562,14 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
             {
                 // c0 = -(s_hat . a) + NTT(m+e)   (ckks_sym.c:273-300); a was written to c1
                 uint32_t a[16], w[16], wp[16], out[16];
-#ifndef SEAMD_NO_PREFETCH_A
                 if constexpr (QUADS)
                 {
 #pragma unroll
                     for (int e = 0; e < 16; e++) a[e] = a_pre[e];
                 }
                 else
-#endif
-                ld_poly<QUADS>(a, A.c1 + pb, tg);
-#ifdef SEAMD_PREFETCH_PAIRS
-                if constexpr (QUADS)
-                {
-#pragma unroll
-                    for (int e = 0; e < 16; e++) w[e] = w_pre[e], wp[e] = wp_pre[e];
-                }
-                else
-#endif
-#ifdef SEAMD_ABL_NOPAIRS   // timing ablation (WRONG results): what the key-pair loads of the symmetric epilogue cost
-                {
-#pragma unroll
-                    for (int e = 0; e < 16; e++) w[e] = 12345u + e + tg, wp[e] = 54321u * e;
-                }
-#else
+                    ld_poly<QUADS>(a, A.c1 + pb, tg);
                 ld_pairs<QUADS>(w, wp, T.s_hat + kb, tg);
-#endif
 #pragma unroll
                 for (int e = 0; e < 16; e++) out[e] = sub_mul_canon(x[e], a[e], w[e], wp[e], q, two_q);
                 st_poly<QUADS>(A.c0 + pb, out, tg);
@@ -665,19 +588,8 @@ template <int LOGN, int MODE, bool GENERAL>
 constexpr int enc_blocks()
 {
     if (LOGN > 12) return 1;
-#ifdef SEAMD_ASYM_SERIAL4
-    if (MODE == kModeAsym) return GENERAL ? 2 : SEAMD_ASYM_SERIAL4;
-#endif
-#ifndef SEAMD_NO_ASYM3_ALIAS
     if (MODE == kModeAsym && !GENERAL) return 3;   // transpose region inside the planes (encrypt_one, QALIAS)
-#endif
     if (MODE == kModeAsym) return 2;   // 3 (with the transpose region aliased) spills: 5.45 -> 7.07 ms
-#ifdef SEAMD_ABL_SYM_BLOCKS   // A/B only: register budget of the symmetric / encode-only fast form for this many workgroups per CU
-    if (!GENERAL) return SEAMD_ABL_SYM_BLOCKS;
-#endif
-#ifdef SEAMD_SYM5
-    if (!GENERAL) return 5;
-#endif
     return GENERAL ? 3 : 4;
 }
 
@@ -805,19 +717,10 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     constexpr int N    = G::N;
     constexpr int CTOP = LOGN - 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef SEAMD_NTT_FUSE_PRIO
-    SEAMD_SETPRIO(SEAMD_NTT_FUSE_PRIO);
-#endif
     uint32_t *lds32  = reinterpret_cast<uint32_t *>(smem);
     const int t      = threadIdx.x;
     const size_t b   = blockIdx.x;
     const int np     = P.nprimes;
-#ifdef SEAMD_ABL_NTT_PAIR   // A/B build: j + 256 = primes j and j + 1 in ONE launch (the int32 row is read from HBM once)
-    const int jpair_first = j & 255, jpair_n = (j >> 8) + 1;
-    for (int jpair = 0; jpair < jpair_n; jpair++) { j = jpair_first + jpair; if (jpair) __syncthreads();
-    __asm__ volatile("" : "+s"(j));                 // nothing of one iteration's addressing is carried into the other
-    const int t = opaque_index((int)threadIdx.x);   // (shadows the kernel's t on purpose)
-#endif
     const uint32_t q = P.q[j], two_q = q << 1;
     uint32_t *poly   = A.c0 + (b * np + j) * N;
 
@@ -878,9 +781,6 @@ __attribute__((amdgpu_waves_per_eu(LOGN == 14 ? 5 : (XformGeom<LOGN>::THREADS + 
     {
         store_quads(poly, x, t);
     }
-#ifdef SEAMD_ABL_NTT_PAIR
-    }
-#endif
 }
 
 // Batched stand-alone forward NTT (ntt_inpl, ntt.c:168-189) of `count` polynomials mod q_j,
@@ -1083,24 +983,10 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
     size_t shmem_fast = planes, shmem_gen = planes;
     if (LOGN <= 12)
     {
-#ifdef SEAMD_ASYM_SERIAL4
-        const size_t ntt_planes = (size_t)G::SLOTS * sizeof(uint32_t);
-#else
         const size_t ntt_planes = (size_t)(MODE == kModeAsym ? 3 : 1) * G::SLOTS * sizeof(uint32_t);
-#endif
-#if defined(SEAMD_SYM5)
-        // half-plane encoder exchanges (sym / encode-only), transpose region aliased into the plane(s)
-        shmem_fast = MODE == kModeAsym ? std::max(planes, std::max(ntt_planes, quads)) : std::max(ntt_planes, quads);
-#elif defined(SEAMD_QALIAS28)
-        shmem_fast = std::max(planes, std::max(ntt_planes, quads));
-#elif !defined(SEAMD_NO_ASYM3_ALIAS) && !defined(SEAMD_ASYM_SERIAL4)
-        // public key: the transpose region is aliased into the three planes (encrypt_one, QALIAS); the serial A/B
-        // build (SEAMD_ASYM_SERIAL4) has no alias and takes the plane + region sizing below
+        // public key: the transpose region is aliased into the three planes (encrypt_one, QALIAS)
         shmem_fast = MODE == kModeAsym ? std::max(planes, std::max(ntt_planes, quads)) : std::max(planes, ntt_planes + quads);
-#else
-        shmem_fast = std::max(planes, ntt_planes + quads);
-#endif
-        // (general forms never alias the region: the A/B builds that alias it in the fast form size them separately)
+        // (the general forms never alias the region; the general public-key form keeps the tile layout)
         shmem_gen  = MODE == kModeAsym ? std::max(planes, ntt_planes) : std::max(planes, ntt_planes + quads);
     }
     hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);

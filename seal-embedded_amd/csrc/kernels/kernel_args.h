@@ -8,16 +8,6 @@
 
 namespace seamd {
 
-// Wave priorities of the per-prime pipeline (s_setprio; -DSEAMD_PRIO_OFF builds without them for A/B runs).
-// The chain launches are the critical path of a symmetric step: their waves win the VALU arbitration (3), the
-// per-prime transform kernel, which must keep pace with them, comes next (2), the throughput samplers (CBD,
-// redraw candidates) take what is left (0, the default).
-#ifdef SEAMD_PRIO_OFF
-#define SEAMD_SETPRIO(p) ((void)0)
-#else
-#define SEAMD_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
-#endif
-
 struct EncArgs
 {
     const float *values;
@@ -62,13 +52,6 @@ struct UniformArgs
                               // ciphertexts of ALL guessed primes of the prime speculation in ONE launch
     uint32_t *nrej;           // staged form only: [B] rejected coefficients of the polynomial (k_bulk_pair ->
                               // k_resolve_wave)
-    // Staged-LANE form (round 5): the redraw candidates of ALL primes of a ciphertext are one window of its counter
-    // stream, V[b][k] = block(1 + k)[0:4] for k < spec_window (a candidate is a function of (seed, counter) only, not
-    // of the prime; the counters the bulk blocks of primes >= 1 take are computed and never read).  Row b of `spec`
-    // is spec_stride words long and holds spec_window valid candidates; the resolve kernels of the prime that
-    // starts at counter c = ctr_in[b] walk it from offset c, at most spec_cap candidates deep.  0 = per-prime rows.
-    uint32_t spec_window;
-    uint32_t spec_stride;
     // staged forms: [1 + B] count + indices of the ciphertexts k_resolve_light could not finish (candidate row too
     // short, reject list overflowed); zeroed by the bulk kernel of the same prime, walked by a SMALL grid of
     // k_resolve_wave (a full grid of waves that read one word and leave cost 0.35-1.0 ms beside the throughput
@@ -116,12 +99,7 @@ hipError_t launch_make_pairs(const uint32_t *vals, uint32_t *pairs, uint32_t q, 
 hipError_t launch_sample_uniform(const DevParams &, const UniformArgs &, hipStream_t);
 // staged form, one prime per launch (kernels/samplers.hip: k_bulk_pair, k_candidates, k_resolve_wave)
 hipError_t launch_uniform_bulk_pair(const DevParams &, const UniformArgs &, hipStream_t);
-// candidates k_lo <= k < k_lo + k_cnt of every row (default: the whole row, spec_cap candidates)
-hipError_t launch_uniform_candidates(const UniformArgs &, hipStream_t, uint32_t k_lo = 0, uint32_t k_cnt = 0xFFFFFFFFu);
-// staged-lane form: the bulk squeeze of one prime, ONE ciphertext per LANE (k_bulk_lane)
-hipError_t launch_uniform_bulk_lane(const DevParams &, const UniformArgs &, hipStream_t);
-// ... with TWO chain waves per SIMD kept in phase (k_bulk_lane_sync: keccak_f1600_sync), on half as many CUs
-hipError_t launch_uniform_bulk_lane_sync(const DevParams &, const UniformArgs &, hipStream_t);
+hipError_t launch_uniform_candidates(const UniformArgs &, hipStream_t);
 hipError_t launch_uniform_resolve(const DevParams &, const UniformArgs &, hipStream_t);
 // Small-batch prime speculation (se_context.cpp, encrypt_sym_small): the uniform sampler of prime
 // j >= 1 is run for every plausible start counter of a window at once ("virtual ciphertexts"), so

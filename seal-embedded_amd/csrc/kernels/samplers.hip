@@ -67,11 +67,7 @@ constexpr uint32_t kRejMarker = 0xFFFFFFFFu;  // >= every modulus, never a valid
 
 // Workgroup size of the one-permutation-per-thread kernels (k_sample_cbd, k_candidates): 512 threads are two waves per
 // SIMD and workgroup, which the phase-synchronised permutation of keccak_sync.cuh keeps in phase.
-#ifdef SEAMD_CBD_NOSYNC
-constexpr int kCbdThreads = 256;
-#else
 constexpr int kCbdThreads = 512;
-#endif
 
 // MAXT: the largest workgroup the instantiation is launched with.  Up to 8 waves per workgroup (every
 // batch <= 4 x 64 x CUs, i.e. all BASELINE shapes) the kernel may use 256 VGPRs: 160, no spills; the
@@ -89,9 +85,6 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
     // dynamic LDS: reserved (> 80 KiB) to pin one workgroup per CU; its first bytes hold the
     // per-wave rank -> lane table of the balanced redraw phase
     extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];
-#ifdef SEAMD_ABL_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(SEAMD_ABL_CHAIN_PRIO);   // A/B only: chain waves above the CBD waves beside them
-#endif
     const int lane      = threadIdx.x & 63;
     const int wave      = threadIdx.x >> 6;
     uint8_t *rank2lane  = pin_lds + wave * 64;
@@ -658,266 +651,36 @@ __global__ __launch_bounds__(512) void k_bulk_pair(DevParams P, UniformArgs A)
     if (A.flagged && blockIdx.x == 0 && threadIdx.x == 0) A.flagged[0] = 0;   // read by this prime's k_resolve_wave
 }
 
-// ------------------------------------------------------------------------------------------
-// Staged-LANE form (round 5): the bulk squeeze of ONE prime with one ciphertext per LANE -- phase 1 of
-// k_sample_uniform and nothing else (no candidate permutations inside the chain, no redraw phase, the seed is
-// dead after the absorb: ~100 VGPRs instead of 160).  Of a symmetric ciphertext's 606 chain permutations at n = 4096
-// only these 3 x 121 are sequential by the reference's semantics (sample.c:48-56); the 243 redraw candidates are
-// independent SHAKE calls and run as a phase-synchronised throughput kernel beside the chains (k_candidates over the
-// ciphertext's whole counter window), the resolve step is k_resolve_light / k_resolve_wave as in the pair form.
-// Writes residues / markers, the reject list and the reject count; same conventions as k_bulk_pair.
-// ------------------------------------------------------------------------------------------
-template <int LOGN>
-__global__ __launch_bounds__(512) void k_bulk_lane(DevParams P, UniformArgs A)
-{
-    constexpr int N          = 1 << LOGN;
-    constexpr int FULL_STEPS = (N * 4) / 136;
-    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;
-    static_assert(TAIL_WORDS % 2 == 0 && TAIL_WORDS <= 32, "the tail fits one mask");
-    extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];   // reserved: one workgroup per CU
-    (void)pin_lds;
-    const size_t bq   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = bq < A.B;
-    if (A.flagged && bq == 0) A.flagged[0] = 0;   // read by this prime's k_resolve_wave
-    if (!__any(active)) return;
-    const size_t b   = active ? bq : (size_t)A.B - 1;   // idle lanes shadow the last ciphertext, store nothing
-    const uint32_t j = A.prime_lo;
-    const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
-    uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
-    uint32_t *mylist = A.rej_list + b * A.rej_cap;
-    KeccakState st;
-    {
-        uint32_t seed[16];
-        load_seed(seed, A.seeds, b);
-        prng_absorb(st, seed, A.ctr_in ? A.ctr_in[b] : 0);
-    }
-    uint32_t nrej = 0;
-    if (active)
-    {
-        // branch-free reject test / reduction of a word and the per-step flush of the reject masks: see k_sample_uniform
-        auto word = [&](auto r4, uint32_t x, uint32_t &mask) -> uint32_t {
-            const bool rej   = x >= bound;
-            const uint32_t r = reduce_sample<decltype(r4)::value>(x, q, crh);
-            mask             = (mask << 1) | (rej ? 1u : 0u);
-            return rej ? kRejMarker : r;
-        };
-        const bool red4 = (uint64_t)bound <= 4ull * q;   // uniform per prime
-        auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
-            while (__any(mask != 0))
-            {
-                if (mask != 0)
-                {
-                    const uint32_t p = (uint32_t)__clz((int)mask);
-                    mask &= ~(0x80000000u >> p);
-                    if (nrej < A.rej_cap) mylist[nrej] = first_pos + (p - (32u - count));
-                    nrej++;
-                }
-            }
-        };
-        uint32_t idx = 0;
-        for (int step = 0; step < FULL_STEPS; step++)
-        {
-            keccak_f1600(st);
-            uint32_t m0 = 0, m1 = 0;   // words 0..31 / 32..33 of this step
-            auto emit = [&](auto r4) {
-#pragma unroll
-                for (int i = 0; i < 17; i++)
-                {
-                    uint32_t &mk = (i < 16) ? m0 : m1;
-                    uint32_t w0  = word(r4, st.lo[i], mk);
-                    uint32_t w1  = word(r4, st.hi[i], mk);
-                    *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-                }
-            };
-            if (red4)
-                emit(std::true_type{});
-            else
-                emit(std::false_type{});
-            if (__any((m0 | m1) != 0))
-            {
-                flush(m0, 32, idx);
-                flush(m1, 2, idx + 32);
-            }
-            idx += 34;
-        }
-        if constexpr (TAIL_WORDS > 0)
-        {
-            keccak_f1600(st);
-            uint32_t m0 = 0;
-#pragma unroll
-            for (int i = 0; i < TAIL_WORDS / 2; i++)
-            {
-                uint32_t w0 = word(std::false_type{}, st.lo[i], m0);
-                uint32_t w1 = word(std::false_type{}, st.hi[i], m0);
-                *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-            }
-            flush(m0, TAIL_WORDS, idx);
-        }
-        A.nrej[b] = nrej;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// PAIRED chains (round 5): k_bulk_lane with TWO chain waves per SIMD that stay in phase.  A lone chain wave issues one
-// instruction per ~4.4-5 cycles whatever its opcode; two waves of a SIMD that present the same
-// issue class at the same time share slots (v_xor 2.1, v_bitop3 2.8 cycles).  So the chains of a batch are packed two
-// per SIMD into 512-thread workgroups -- HALF as many CUs as one wave per SIMD would take, the other half of the chip
-// is left to the throughput kernels (candidates, CBD) -- and squeeze with the phase-synchronised FULL permutation of
-// keccak_sync.cuh (keccak_f1600_sync: state in / state out, 96 workgroup barriers).  Every live wave of a workgroup
-// runs the same number of permutations (FULL_STEPS + 1); waves without a ciphertext end before the first barrier.
-// Same outputs as k_bulk_lane (reject list, reject count, residues / markers).
-// ------------------------------------------------------------------------------------------
-// HOG: the kernel claims all 256 VGPRs a wave may have, so that two chain waves fill a SIMD's register file and no
-// other kernel's waves become resident beside them (throughput waves on the same SIMD take issue slots from the pair:
-// measured, the chain step stretches from ~13 to ~20 us).
-template <int LOGN, bool HOG>
-__global__ __launch_bounds__(512) void k_bulk_lane_sync(DevParams P, UniformArgs A)
-{
-    constexpr int N          = 1 << LOGN;
-    constexpr int FULL_STEPS = (N * 4) / 136;
-    constexpr int TAIL_WORDS = N - FULL_STEPS * 34;
-    static_assert(TAIL_WORDS % 2 == 0 && TAIL_WORDS <= 32, "the tail fits one mask");
-    extern __shared__ __attribute__((aligned(16))) unsigned char pin_lds[];   // reserved: one workgroup per CU
-    (void)pin_lds;
-    if constexpr (HOG) asm volatile("v_mov_b32 v255, 0" ::: "v255");
-    if (A.debug_flags & 131072u) __builtin_amdgcn_s_setprio(3);   // A/B: the chain pair above every other wave of its SIMD
-    const size_t bq   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = bq < A.B;
-    if (A.flagged && bq == 0) A.flagged[0] = 0;   // read by this prime's k_resolve_wave
-    if (!__any(active)) return;                   // whole waves without a ciphertext END before the first barrier
-    const size_t b   = active ? bq : (size_t)A.B - 1;   // idle lanes shadow the last ciphertext, store nothing
-    const uint32_t j = A.prime_lo;
-    const uint32_t q = P.q[j], crh = P.cr_hi[j], bound = P.bound[j];
-    uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
-    uint32_t *mylist = A.rej_list + b * A.rej_cap;
-    uint32_t s[50];   // lane i of the state = (s[2 i], s[2 i + 1])
-    {
-        uint32_t seed[16];
-        load_seed(seed, A.seeds, b);
-        KeccakState st;
-        prng_absorb(st, seed, A.ctr_in ? A.ctr_in[b] : 0);
-#pragma unroll
-        for (int i = 0; i < 25; i++) s[2 * i] = st.lo[i], s[2 * i + 1] = st.hi[i];
-    }
-    uint32_t nrej = 0;
-    auto word = [&](auto r4, uint32_t x, uint32_t &mask) -> uint32_t {
-        const bool rej   = x >= bound;
-        const uint32_t r = reduce_sample<decltype(r4)::value>(x, q, crh);
-        mask             = (mask << 1) | (rej ? 1u : 0u);
-        return rej ? kRejMarker : r;
-    };
-    const bool red4 = (uint64_t)bound <= 4ull * q;   // uniform per prime
-    auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
-        while (__any(mask != 0))
-        {
-            if (mask != 0)
-            {
-                const uint32_t p = (uint32_t)__clz((int)mask);
-                mask &= ~(0x80000000u >> p);
-                if (active && nrej < A.rej_cap) mylist[nrej] = first_pos + (p - (32u - count));
-                nrej++;
-            }
-        }
-    };
-    uint32_t idx = 0;
-    for (int step = 0; step < FULL_STEPS; step++)
-    {
-        keccak_f1600_sync(s, &kKeccakRC[0][0]);
-        uint32_t m0 = 0, m1 = 0;   // words 0..31 / 32..33 of this step
-        auto emit = [&](auto r4) {
-#pragma unroll
-            for (int i = 0; i < 17; i++)
-            {
-                uint32_t &mk = (i < 16) ? m0 : m1;
-                uint32_t w0  = word(r4, s[2 * i], mk);
-                uint32_t w1  = word(r4, s[2 * i + 1], mk);
-#ifdef SEAMD_ABL_PAIR_NOSTORE   // timing ablation (WRONG results): what the emit's store burst costs a chain pair
-                if (active && (w0 ^ w1) == 0x12345u) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-#else
-                if (active) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-#endif
-            }
-        };
-        if (red4)
-            emit(std::true_type{});
-        else
-            emit(std::false_type{});
-        if (__any((m0 | m1) != 0))
-        {
-            flush(m0, 32, idx);
-            flush(m1, 2, idx + 32);
-        }
-        idx += 34;
-    }
-    if constexpr (TAIL_WORDS > 0)
-    {
-        keccak_f1600_sync(s, &kKeccakRC[0][0]);
-        uint32_t m0 = 0;
-#pragma unroll
-        for (int i = 0; i < TAIL_WORDS / 2; i++)
-        {
-            uint32_t w0 = word(std::false_type{}, s[2 * i], m0);
-            uint32_t w1 = word(std::false_type{}, s[2 * i + 1], m0);
-            if (active) *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
-        }
-        flush(m0, TAIL_WORDS, idx);
-    }
-    if (active) A.nrej[b] = nrej;
-}
-
-// candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4]; consecutive threads = consecutive k of one ciphertext.
-// Round 4: 512-thread workgroups and the phase-synchronised permutation, as k_sample_cbd (-DSEAMD_CBD_NOSYNC: round 3).
-// A launch covers candidates k_lo <= k < k_lo + k_cnt of every row of `stride` words (the staged-lane form fills a
-// ciphertext's window in a few launches, the earliest counters first).
-__global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A, uint32_t k_lo, uint32_t k_cnt, uint32_t stride)
+// candidates V[b][k] = block(ctr_in[b] + 1 + k)[0:4], k < spec_cap; consecutive threads = consecutive k of one
+// ciphertext.  512-thread workgroups and the phase-synchronised permutation, as k_sample_cbd.
+__global__ __launch_bounds__(kCbdThreads) void k_candidates(UniformArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)A.B * k_cnt;
-#ifndef SEAMD_CBD_NOSYNC
+    const size_t total = (size_t)A.B * A.spec_cap;
     if (!__any(gid < total)) return;   // whole waves past the end END before the first barrier ...
-#endif
     if (gid >= total) return;          // ... lanes of a partial wave are masked, the wave runs the permutation
     // (hipcc folds the two tests into one exec-masked region with a branch to s_endpgm: either way a wave that does not
     // run the block has ended -- the contract of keccak_sync.cuh, checked on the ISA by tests/test_keccak_sync.py)
-    const size_t b   = gid / k_cnt;
-    const uint32_t k = k_lo + (uint32_t)(gid - b * k_cnt);
+    const size_t b   = gid / A.spec_cap;
+    const uint32_t k = (uint32_t)(gid - b * A.spec_cap);
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
     const uint64_t ctr = (A.ctr_in ? A.ctr_in[b] : 0) + 1 + k;
-#ifdef SEAMD_CBD_NOSYNC
-    KeccakState st;
-    prng_absorb(st, seed, ctr);
-    keccak_f1600_fresh<true>(st);   // only the first word is consumed
-    A.spec[b * stride + k] = st.lo[0];
-#else
     uint32_t w[18];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = seed[i];
     w[16] = (uint32_t)ctr;
     w[17] = (uint32_t)(ctr >> 32);
     keccak_fresh4_sync(w, &kKeccakRC[0][0]);
-    A.spec[b * stride + k] = w[0];
-#endif
+    A.spec[gid] = w[0];
 }
 
-// The candidate row of ciphertext b for the prime that starts at counter c (its bulk block took c, the redraw
-// candidates are the counters c + 1, c + 2, ...): per-prime rows (k_candidates ran with this prime's start counters)
-// or, in the staged-lane form, the ciphertext's window from offset c on (UniformArgs::spec_window).
-__device__ __forceinline__ const uint32_t *candidate_row(const UniformArgs &A, size_t b, uint64_t c, uint32_t &row_len)
+// The candidate row of ciphertext b (k_candidates ran with this prime's start counters: the bulk block took counter c,
+// the candidates are the counters c + 1, c + 2, ...).
+__device__ __forceinline__ const uint32_t *candidate_row(const UniformArgs &A, size_t b, uint32_t &row_len)
 {
-    if (!A.spec)
-    {
-        row_len = 0;
-        return nullptr;
-    }
-    if (A.spec_window == 0)
-    {
-        row_len = A.spec_cap;
-        return A.spec + b * (size_t)A.spec_cap;
-    }
-    const uint32_t off = c < (uint64_t)A.spec_window ? (uint32_t)c : A.spec_window;
-    row_len            = min(A.spec_cap, A.spec_window - off);
-    return A.spec + b * (size_t)A.spec_stride + off;
+    row_len = A.spec ? A.spec_cap : 0u;
+    return A.spec ? A.spec + b * (size_t)A.spec_cap : nullptr;
 }
 
 // The common case of the resolve step without any Keccak in the kernel (24 VGPRs instead of 130: 8 waves per
@@ -938,7 +701,7 @@ __global__ __launch_bounds__(256) void k_resolve_light(DevParams P, UniformArgs 
     const uint64_t c0   = A.ctr_in ? A.ctr_in[b] : 0;
     uint64_t ctr        = c0 + 1;   // the bulk block took one counter
     uint32_t row_len;
-    const uint32_t *row   = candidate_row(A, b, c0, row_len);
+    const uint32_t *row   = candidate_row(A, b, row_len);
     const uint32_t rounds = (row_len + 63u) / 64u;
     auto flag = [&]() {
         if (lane == 0)
@@ -1013,7 +776,7 @@ __global__ __launch_bounds__(256) void k_resolve_wave(DevParams P, UniformArgs A
             load_seed(seed, A.seeds, b);
             uint32_t *mypoly = A.out + (b * A.out_primes + (j - A.out_prime_base)) * (size_t)N;
             uint32_t row_len;
-            const uint32_t *row = candidate_row(A, b, c0, row_len);
+            const uint32_t *row = candidate_row(A, b, row_len);
             wave_redraws<N>(P.q[j], P.cr_hi[j], P.bound[j], mypoly, A.rej_list + b * A.rej_cap, A.rej_cap, need, seed, ctr,
                             row, row_len, lane);
         }
@@ -1132,43 +895,26 @@ __device__ __forceinline__ uint32_t byte_window(const uint32_t (&w)[24], int byt
 
 // Round 4: 512-thread workgroups (two waves per SIMD and workgroup) and the phase-synchronised permutation of
 // keccak_sync.cuh -- waves of one SIMD only pair their v_xor / v_bitop3 when they are in the same phase of the round
-// (profiles/r04_ubench7_keccak_schedules.txt).  -DSEAMD_CBD_NOSYNC builds the round-3 form for the A/B.
+// (profiles/r04_ubench7_keccak_schedules.txt).
 __global__ __launch_bounds__(kCbdThreads) void k_sample_cbd(CbdArgs A)
 {
     const size_t gid   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.B * A.blocks_per_ct;
-#ifndef SEAMD_CBD_NOSYNC
     if (!__any(gid < total)) return;   // whole waves past the end END before the first barrier ...
-#endif
     if (gid >= total) return;          // ... lanes of a partial wave are masked, the wave runs the permutation
     // (hipcc folds the two tests into one exec-masked region with a branch to s_endpgm: either way a wave that does not
     // run the block has ended -- the contract of keccak_sync.cuh, checked on the ISA by tests/test_keccak_sync.py)
-#ifdef SEAMD_ABL_CBD_PRIO
-    __builtin_amdgcn_s_setprio(SEAMD_ABL_CBD_PRIO);   // A/B only: CBD waves above the chain waves they share SIMDs with
-#endif
     const size_t b   = gid / A.blocks_per_ct;
     const uint32_t k = (uint32_t)(gid - b * A.blocks_per_ct);
     uint32_t seed[16];
     load_seed(seed, A.seeds, b);
     uint64_t ctr = (A.ctr_base ? A.ctr_base[b] : 0) + k;
     uint32_t w[24];
-#ifdef SEAMD_CBD_NOSYNC
-    KeccakState st;
-    prng_absorb(st, seed, ctr);
-    keccak_f1600_fresh<true>(st);  // only 96 of the 200 state bytes are consumed (folded theta: keccak.cuh)
-#pragma unroll
-    for (int i = 0; i < 12; i++)
-    {
-        w[2 * i]     = st.lo[i];
-        w[2 * i + 1] = st.hi[i];
-    }
-#else
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = seed[i];
     w[16] = (uint32_t)ctr;
     w[17] = (uint32_t)(ctr >> 32);
     keccak_fresh96_sync(w, &kKeccakRC[0][0]);
-#endif
     // sample i = popcnt(bytes 6i,6i+1, low 5 bits of 6i+2) - popcnt(bytes 6i+3,6i+4, low 5 of 6i+5)
     uint32_t packed[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1691,65 +1437,11 @@ hipError_t launch_uniform_bulk_pair(const DevParams &P, const UniformArgs &A, hi
     return hipGetLastError();
 }
 
-hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st, uint32_t k_lo, uint32_t k_cnt)
+hipError_t launch_uniform_candidates(const UniformArgs &A, hipStream_t st)
 {
-    if (k_cnt == 0xFFFFFFFFu) k_lo = 0, k_cnt = A.spec_cap;
-    const uint32_t stride = A.spec_window ? A.spec_stride : A.spec_cap;
-    const size_t total    = (size_t)A.B * k_cnt;
+    const size_t total = (size_t)A.B * A.spec_cap;
     if (total == 0 || !A.spec) return hipSuccess;
-    if (k_lo + k_cnt > stride) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A,
-                       k_lo, k_cnt, stride);
-    return hipGetLastError();
-}
-
-hipError_t launch_uniform_bulk_lane_sync(const DevParams &P, const UniformArgs &A, hipStream_t st)
-{
-    if (A.B == 0) return hipSuccess;
-    if (!A.nrej || A.prime_hi != A.prime_lo + 1) return hipErrorInvalidValue;
-    // 8 waves per workgroup = two per SIMD; 84 KiB of reserved LDS: one workgroup per CU
-    const unsigned threads = 512, grid = (unsigned)(((size_t)A.B + threads - 1) / threads);
-    const size_t lds = 84 * 1024;
-#define SEAMD_LAUNCH_BULK_SYNC_H(L, H)                                                                                     \
-    (void)hipFuncSetAttribute((const void *)k_bulk_lane_sync<L, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_bulk_lane_sync<L, H>), dim3(grid), dim3(threads), lds, st, P, A)
-#define SEAMD_LAUNCH_BULK_SYNC(L) \
-    if (A.debug_flags & 65536u) { SEAMD_LAUNCH_BULK_SYNC_H(L, true); } else { SEAMD_LAUNCH_BULK_SYNC_H(L, false); }
-    switch (P.logn)
-    {
-        case 10: SEAMD_LAUNCH_BULK_SYNC(10); break;
-        case 11: SEAMD_LAUNCH_BULK_SYNC(11); break;
-        case 12: SEAMD_LAUNCH_BULK_SYNC(12); break;
-        case 13: SEAMD_LAUNCH_BULK_SYNC(13); break;
-        case 14: SEAMD_LAUNCH_BULK_SYNC(14); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef SEAMD_LAUNCH_BULK_SYNC
-#undef SEAMD_LAUNCH_BULK_SYNC_H
-    return hipGetLastError();
-}
-
-hipError_t launch_uniform_bulk_lane(const DevParams &P, const UniformArgs &A, hipStream_t st)
-{
-    if (A.B == 0) return hipSuccess;
-    if (!A.nrej || A.prime_hi != A.prime_lo + 1) return hipErrorInvalidValue;
-    unsigned threads, grid;
-    size_t lds;
-    chain_geometry(A.B, P.num_cus, threads, grid, lds);
-    if (threads > 512) return hipErrorInvalidValue;   // the form is for batches of up to 8 chain waves per CU
-#define SEAMD_LAUNCH_BULK_LANE(L)                                                                                  \
-    (void)hipFuncSetAttribute((const void *)k_bulk_lane<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_bulk_lane<L>), dim3(grid), dim3(threads), lds, st, P, A)
-    switch (P.logn)
-    {
-        case 10: SEAMD_LAUNCH_BULK_LANE(10); break;
-        case 11: SEAMD_LAUNCH_BULK_LANE(11); break;
-        case 12: SEAMD_LAUNCH_BULK_LANE(12); break;
-        case 13: SEAMD_LAUNCH_BULK_LANE(13); break;
-        case 14: SEAMD_LAUNCH_BULK_LANE(14); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef SEAMD_LAUNCH_BULK_LANE
+    hipLaunchKernelGGL(k_candidates, dim3((unsigned)((total + kCbdThreads - 1) / kCbdThreads)), dim3(kCbdThreads), 0, st, A);
     return hipGetLastError();
 }
 
@@ -1791,7 +1483,6 @@ hipError_t launch_sample_cbd(const CbdArgs &A, hipStream_t st)
 hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
 {
     if (A.B == 0) return hipSuccess;
-#ifndef SEAMD_TERNARY_NOWINDOW   // A/B builds: the chain forms of rounds 1-3 only
     if (!(A.debug_flags & (32 | 64)))
     {
         // Window form (k_sample_ternary_window): W = blocks + mean + 4.7 sigma of the redraws (2 of 256 byte values are
@@ -1813,7 +1504,6 @@ hipError_t launch_sample_ternary(const TernaryArgs &A, hipStream_t st)
             return hipGetLastError();
         }
     }
-#endif
     if (A.B <= uniform_wave_limit(A.num_cus) && !(A.debug_flags & 32))
     {
         // a handful of chains: one wave per ciphertext (see k_sample_uniform_wave)

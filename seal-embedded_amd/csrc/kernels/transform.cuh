@@ -82,136 +82,31 @@ struct XformGeom
     static constexpr int ntt_c(int p) { return (LOGN - 4 - 4 * p > 0) ? LOGN - 4 - 4 * p : 0; }
 };
 
-// Re-deal 16 values per thread from tile layout C_FROM to tile layout C_TO through `lds`.
+// Re-deal 16 values per thread from tile layout C_FROM to tile layout C_TO through `lds`: write, barrier, read,
+// barrier (leaves the workgroup synchronised and `lds` free for reuse).
 //
 // lds_slot() is additive over disjoint bit fields (shifts distribute over OR), so the slot of point
 // tile_index<C>(t, e) is slot(thread part) + slot(e << C): ONE base register per deal and sixteen
 // compile-time offsets that land in the instructions' immediate fields.  Written as slot(tile_index(t, e))
 // the compiler does not see this: it computed the 16 addresses of every deal separately and, in the fused
 // kernels, kept them in registers across the prime loop (64 VGPRs of addresses for the two NTT exchanges).
-//
-// Synchronisation (SYNC):
-//   kSyncBoth  write, barrier, read, barrier: leaves the workgroup synchronised and `lds` free for reuse.
-//   kSyncLead  barrier, write, barrier, read: the barrier that protects the buffer from the NEXT writer is
-//              that writer's own leading one -- it is reached long after the slowest wave's reads, so it
-//              costs little, and an exchange that needs no workgroup barrier at all (kLocal) need not pay
-//              for its neighbours' (half the kernel's wave-cycles were waits).
-//   kLocal     an exchange between window 0 and a window <= 4 stays inside groups of 2^C consecutive
-//              threads, i.e. inside ONE wave, and lds_slot() keeps a wave's 1 024 points in one contiguous
-//              chunk: no workgroup barrier, only wave-level ordering (LDS executes a wave's accesses in
-//              order).  `lds` + wave * WSTRIDE elements is the wave's private chunk; the caller guarantees
-//              that no OTHER wave touches it (a kSyncLead exchange on the same buffer does: its leading
-//              barrier is behind every wave's local reads in program order).
-enum RedealSync { kSyncBoth, kSyncLead, kLocal };
-
-template <int C_FROM, int C_TO, RedealSync SYNC = kSyncBoth, int WSTRIDE = 0, typename T>
+// (Measured and not adopted -- experiments/: leading barriers + wave-local first / last exchanges, neutral;
+// the window 4 -> 0 exchange as a DPP register transpose, +1.5 %; FP64 exchanges through a half-size plane.)
+template <int C_FROM, int C_TO, typename T>
 __device__ __forceinline__ void redeal(T (&v)[16], T *lds, int t)
 {
-#ifdef SEAMD_ABL_NOLDS   // timing ablation (WRONG results): exchanges cost nothing
-    return;
-#endif
-    if constexpr (SYNC == kLocal)
-    {
-        static_assert((C_FROM == 0 && C_TO <= 4) || (C_TO == 0 && C_FROM <= 4), "wave-local exchanges only");
-        constexpr int WS = WSTRIDE ? WSTRIDE : lds_slot<C_FROM, C_TO>(1024);
-        static_assert(WS >= lds_slot<C_FROM, C_TO>(1023) + 1, "a wave's chunk holds its 1 024 points");
-        lds += (t >> 6) * WS;
-        t &= 63;
-    }
-    if constexpr (SYNC == kSyncLead) __syncthreads();
     T *wr = lds + lds_slot<C_FROM, C_TO>(tile_index<C_FROM>(t, 0));
     static_for<0, 16>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         wr[lds_slot<C_FROM, C_TO>(e << C_FROM)] = v[e];
     });
-    if constexpr (SYNC == kLocal)
-    {
-        // the reads below fetch OTHER lanes' values: keep the compiler from moving them above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    else
-        __syncthreads();
+    __syncthreads();
     const T *rd = lds + lds_slot<C_FROM, C_TO>(tile_index<C_TO>(t, 0));
     static_for<0, 16>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         v[e] = rd[lds_slot<C_FROM, C_TO>(e << C_TO)];
     });
-    if constexpr (SYNC == kSyncBoth) __syncthreads();
-    if constexpr (SYNC == kLocal)
-    {
-        // ... and a later write of this wave into the same chunk from moving above these reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
-// An FP64 exchange through a buffer of HALF the size: the low and the high 32-bit words of the 16 values cross one
-// after the other through an XformGeom::SLOTS-word plane (twice the LDS instructions and barriers of the 64-bit form,
-// the same bytes).  What it buys is LDS capacity: the encoder's exchange buffer shrinks from 34 to 17 KiB at n = 4096.
-template <int C_FROM, int C_TO, RedealSync SYNC = kSyncBoth>
-__device__ __forceinline__ void redeal_halves(double (&v)[16], uint32_t *lds, int t)
-{
-    uint32_t lo[16], hi[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) lo[e] = (uint32_t)__double2loint(v[e]), hi[e] = (uint32_t)__double2hiint(v[e]);
-    redeal<C_FROM, C_TO, SYNC>(lo, lds, t);
-    redeal<C_FROM, C_TO, SYNC>(hi, lds, t);
-#pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = __hiloint2double((int)hi[e], (int)lo[e]);
-}
-
-// The window 4 -> 0 exchange as a register shuffle (north_star: "wavefront shuffle for the intra-64 twiddle
-// stages"): a 16 x 16 transpose of (slot, lane-within-row) among the 16 lanes of a DPP row -- four butterfly
-// stages, each swapping one slot bit with one lane bit: distance 8 and 4 by v_mov_b32_dpp row_shl / row_shr
-// under bank masks (3 instructions per register pair), distance 2 and 1 by quad_perm + v_cndmask (4 per pair):
-// 112 VALU instructions + DPP hazard slots, against 16 ds_write_b32 + 16 ds_read_b32 for the wave-local LDS
-// form.  Built only under -DSEAMD_SHUFFLE_REDEAL for the A/B (profiles/r03_ab_sync_shuffle.log): the kernels
-// are VALU-issue-limited and the LDS form wins.
-template <int D>
-__device__ __forceinline__ void shuffle_stage_row(uint32_t (&v)[16])
-{
-    static_assert(D == 8 || D == 4, "bank masks select whole 4-lane banks");
-    constexpr int SHL = 0x100 + D, SHR = 0x110 + D;
-    constexpr int BM0 = D == 8 ? 0x3 : 0x5, BM1 = D == 8 ? 0xC : 0xA;   // lanes with the bit clear / set
-    static_for<0, 16>([&](auto rc) {
-        constexpr int r0 = decltype(rc)::value;
-        if constexpr ((r0 & D) == 0)
-        {
-            constexpr int r1 = r0 | D;
-            const uint32_t tmp = v[r1];
-            v[r1] = (uint32_t)__builtin_amdgcn_update_dpp((int)v[r1], (int)v[r0], SHL, 0xF, BM0, false);
-            v[r0] = (uint32_t)__builtin_amdgcn_update_dpp((int)v[r0], (int)tmp, SHR, 0xF, BM1, false);
-        }
-    });
-}
-template <int D>
-__device__ __forceinline__ void shuffle_stage_quad(uint32_t (&v)[16], int lane)
-{
-    static_assert(D == 2 || D == 1, "inside a quad");
-    constexpr int QP = D == 1 ? 0xB1 : 0x4E;   // quad_perm [1,0,3,2] / [2,3,0,1]
-    const bool set   = (lane & D) != 0;
-    static_for<0, 16>([&](auto rc) {
-        constexpr int r0 = decltype(rc)::value;
-        if constexpr ((r0 & D) == 0)
-        {
-            constexpr int r1    = r0 | D;
-            const uint32_t give = set ? v[r0] : v[r1];
-            const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)give, QP, 0xF, 0xF, true);
-            v[r0] = set ? recv : v[r0];
-            v[r1] = set ? v[r1] : recv;
-        }
-    });
-}
-// tile layout 4 -> tile layout 0 inside every group of 16 consecutive threads
-__device__ __forceinline__ void redeal_4_to_0_shuffle(uint32_t (&v)[16], int t)
-{
-    shuffle_stage_row<8>(v);
-    shuffle_stage_row<4>(v);
-    shuffle_stage_quad<2>(v, t);
-    shuffle_stage_quad<1>(v, t);
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -345,13 +240,7 @@ __device__ __forceinline__ void ifft_pass(double (&re)[16], double (&im)[16],
             constexpr int g = decltype(gc)::value;
             // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
             const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
-#ifdef SEAMD_ABL_NOTAB   // timing ablation (WRONG results): no root-table loads; bit 0: window 0, 1: middle, 2: top
-            const double2 w = ((SEAMD_ABL_NOTAB) & (C == 0 ? 1 : (C + 4 >= LOGN ? 4 : 2)))
-                                  ? make_double2(0.7 + idx * 1e-9, 0.7)
-                                  : *reinterpret_cast<const double2 *>(W + 2 * idx);
-#else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
-#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
@@ -386,12 +275,7 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
         static_for<0, groups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             const int idx   = N + ((8 >> b) - 1 + g) * (N / 16) + t;   // thread-major copy (se_types.h)
-#ifdef SEAMD_ABL_NOTAB
-            const double2 w = ((SEAMD_ABL_NOTAB) & 1) ? make_double2(0.7 + idx * 1e-9, 0.7)
-                                                      : *reinterpret_cast<const double2 *>(W + 2 * idx);
-#else
             const double2 w = *reinterpret_cast<const double2 *>(W + 2 * idx);
-#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int r  = decltype(rc)::value;
                 constexpr int e0 = (g << (b + 1)) | r;
@@ -422,52 +306,33 @@ __device__ __forceinline__ void ifft_pass0_real(double (&re)[16], double (&im)[1
 // REAL_IN: the imaginary parts of the input are all +0 (im[] need not be initialised except im[0]).
 // EXACT: the Annex-G product with libgcc's infinity recovery (cmul_annexg) -- for plaintexts that hold NaN or
 // infinite values and for the stand-alone operators, whose caller may pass anything; im[] fully initialised.
-// FAST: the synchronisation diet -- the first exchange (window 0 -> 4) is wave-local, the others lead with
-// their barrier.  Precondition: a workgroup barrier separates the call from any earlier cross-wave use of
-// `plane`.  Postcondition: other waves may still be READING `plane` when a wave returns -- the next
-// cross-wave user of that memory must start with a barrier (kSyncLead, or any __syncthreads).
-// HALF (n <= 4096): the exchanges go through a plane of XformGeom::SLOTS 32-bit words (redeal_halves).
-template <int LOGN, bool REAL_IN = false, bool EXACT = false, bool FAST = false, bool HALF = false>
+template <int LOGN, bool REAL_IN = false, bool EXACT = false>
 __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
                                            const double *__restrict__ W, double *plane, int t)
 {
     using G = XformGeom<LOGN>;
-    constexpr RedealSync FIRST = FAST ? kLocal : kSyncBoth, NEXT = FAST ? kSyncLead : kSyncBoth;
     if constexpr (REAL_IN && !EXACT)
         ifft_pass0_real<LOGN>(re, im, W, t);
     else
         ifft_pass<LOGN, 0, 0, 4, EXACT>(re, im, W, t);
-    if constexpr (HALF)
-    {
-        static_assert(LOGN <= 12 && !FAST, "half-plane exchanges: the three-pass transforms, plain synchronisation");
-        uint32_t *half = reinterpret_cast<uint32_t *>(plane);
-        constexpr int C2 = G::ifft_c(2);
-        redeal_halves<0, 4>(re, half, t);
-        redeal_halves<0, 4>(im, half, t);
-        ifft_pass<LOGN, 4, 0, 4, EXACT>(re, im, W, t);
-        redeal_halves<4, C2>(re, half, t);
-        redeal_halves<4, C2>(im, half, t);
-        ifft_pass<LOGN, C2, 8 - C2, 4, EXACT>(re, im, W, t);
-        return;
-    }
-    redeal<0, 4, FIRST>(re, plane, t);
-    redeal<0, 4, FIRST>(im, plane, t);
+    redeal<0, 4>(re, plane, t);
+    redeal<0, 4>(im, plane, t);
     ifft_pass<LOGN, 4, 0, 4, EXACT>(re, im, W, t);
     if constexpr (LOGN <= 12)
     {
         constexpr int C2 = G::ifft_c(2);  // 6, 7 or 8
-        redeal<4, C2, NEXT>(re, plane, t);
-        redeal<4, C2, NEXT>(im, plane, t);
+        redeal<4, C2>(re, plane, t);
+        redeal<4, C2>(im, plane, t);
         ifft_pass<LOGN, C2, 8 - C2, 4, EXACT>(re, im, W, t);
     }
     else
     {
-        redeal<4, 8, NEXT>(re, plane, t);
-        redeal<4, 8, NEXT>(im, plane, t);
+        redeal<4, 8>(re, plane, t);
+        redeal<4, 8>(im, plane, t);
         ifft_pass<LOGN, 8, 0, 4, EXACT>(re, im, W, t);
         constexpr int C3 = G::ifft_c(3);  // 9 or 10
-        redeal<8, C3, NEXT>(re, plane, t);
-        redeal<8, C3, NEXT>(im, plane, t);
+        redeal<8, C3>(re, plane, t);
+        redeal<8, C3>(im, plane, t);
         ifft_pass<LOGN, C3, 12 - C3, 4, EXACT>(re, im, W, t);
     }
 }
@@ -490,13 +355,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
             constexpr int g = decltype(gc)::value;
             // window 0: the thread-major copy behind the table (se_types.h, xform_table_len)
             const int idx   = (C == 0) ? N + ((8 >> b) - 1 + g) * (N / 16) + t : h + ((thi << (3 - b)) | g);
-#ifdef SEAMD_ABL_NOTAB
-            const uint2 rw  = ((SEAMD_ABL_NOTAB) & (C == 0 ? 1 : (C + 4 >= LOGN ? 4 : 2)))
-                                  ? make_uint2(12345u + idx, 54321u)
-                                  : *reinterpret_cast<const uint2 *>(RW + 2 * idx);
-#else
             const uint2 rw  = *reinterpret_cast<const uint2 *>(RW + 2 * idx);
-#endif
             static_for<0, (1 << b)>([&](auto rc) {
                 constexpr int e0 = (g << (b + 1)) | decltype(rc)::value;
                 constexpr int e1 = e0 | (1 << b);
@@ -508,46 +367,28 @@ __device__ __forceinline__ void ntt_pass(uint32_t (&x)[16], const uint32_t *__re
 
 // Whole NTT: input in tile layout LOGN-4 with values in [0, 2q] (anything < 4q), output in tile
 // layout 0 (thread t holds 16t..16t+15 of the bit-reversed-order result), values in [0,4q).
-// LOCAL_WS > 0: the synchronisation diet -- the cross-wave exchanges lead with their barrier (kSyncLead)
-// and the LAST exchange (window C -> 0: inside groups of 2^C consecutive threads) runs wave-locally in
-// `lds_local`, a region of its own with LOCAL_WS elements per wave (so that it can never meet another wave's
-// cross-wave traffic in `lds`); nobody but the calling wave may use that wave's chunk meanwhile.  Same
-// postcondition as ifft_tiles<FAST>.
-template <int LOGN, int LOCAL_WS = 0>
+template <int LOGN>
 __device__ __forceinline__ void ntt_tiles(uint32_t (&x)[16], const uint32_t *__restrict__ RW,
-                                          uint32_t q, uint32_t *lds, int t, uint32_t *lds_local = nullptr)
+                                          uint32_t q, uint32_t *lds, int t)
 {
     using G              = XformGeom<LOGN>;
     const uint32_t two_q = q << 1;
     constexpr int C0     = LOGN - 4;
     constexpr int C1     = G::ntt_c(1);  // LOGN - 8
-    constexpr bool FAST  = LOCAL_WS > 0;
-    constexpr RedealSync CROSS = FAST ? kSyncLead : kSyncBoth;
     ntt_pass<LOGN, C0, 0, 4>(x, RW, q, two_q, t);
-    redeal<C0, C1, CROSS>(x, lds, t);
+    redeal<C0, C1>(x, lds, t);
     ntt_pass<LOGN, C1, 0, 4>(x, RW, q, two_q, t);
     if constexpr (LOGN <= 12)
     {
-#ifdef SEAMD_SHUFFLE_REDEAL
-        if constexpr (FAST && C1 == 4)
-            redeal_4_to_0_shuffle(x, t);
-        else
-#endif
-        if constexpr (FAST)
-            redeal<C1, 0, kLocal, LOCAL_WS>(x, lds_local, t);
-        else
-            redeal<C1, 0>(x, lds, t);
+        redeal<C1, 0>(x, lds, t);
         ntt_pass<LOGN, 0, 0, C1>(x, RW, q, two_q, t);  // remaining bits C1-1 .. 0
     }
     else
     {
         constexpr int C2 = G::ntt_c(2);  // LOGN - 12 (1 or 2)
-        redeal<C1, C2, CROSS>(x, lds, t);
+        redeal<C1, C2>(x, lds, t);
         ntt_pass<LOGN, C2, 0, 4>(x, RW, q, two_q, t);
-        if constexpr (FAST)
-            redeal<C2, 0, kLocal, LOCAL_WS>(x, lds_local, t);
-        else
-            redeal<C2, 0>(x, lds, t);
+        redeal<C2, 0>(x, lds, t);
         ntt_pass<LOGN, 0, 0, C2>(x, RW, q, two_q, t);
     }
 }

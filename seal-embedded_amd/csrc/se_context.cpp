@@ -96,7 +96,7 @@ Context::~Context()
     wipe_device(d_a, a_cap * np * n * sizeof(uint32_t));
     void *ptrs[] = {d_inv_map, d_ifft_w, d_ntt_rw, d_s_hat, d_pk0, d_pk1, d_intt_rw, d_map, d_gather,
                     d_err,     d_ucodes, d_ctr,    d_rej, d_a,   d_spec, d_general, d_compact,
-                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail, d_sp_prime, d_nrej, d_win, d_flagged};
+                    d_sp_seeds, d_sp_ctr, d_sp_ctrout, d_sp_rows, d_sp_fail, d_sp_prime, d_nrej, d_flagged};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -136,8 +136,6 @@ int Context::init(size_t n, size_t nprimes, int dev)
     // measured on one 256-CU MI355X and are scaled by the CU count; results are bit-identical either way)
     // (kept in members of their own: se_amd_set_debug_flags assigns the whole debug_flags field)
     if (const char *e = getenv("SE_AMD_STAGED")) staged_mode = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SE_AMD_STAGED_LANE")) staged_lane_mode = atoi(e);   // 0 off, 1 lone chains, 2 paired chains
-    if (const char *e = getenv("SE_AMD_WINDOW_SIGMA")) window_sigma = atof(e);
     if (const char *e = getenv("SE_AMD_SPECULATION")) spec_mode = atoi(e) ? 1 : 0;
     dp         = to_dev_params(hp);
     dp.num_cus = (uint32_t)num_cus;
@@ -626,103 +624,6 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
 
     const size_t chain_waves_per_cu = ((B + 63) / 64 + (size_t)num_cus - 1) / (size_t)num_cus;
     const bool split = split_mode == 1 || (split_mode == 2 && (hp.n >= 8192 || chain_waves_per_cu < 4));
-    // Staged-LANE form of the sampler phase (round 5; kernels/samplers.hip: k_bulk_lane): the chain of a ciphertext
-    // keeps only the permutations that ARE sequential (3 x 121 bulk squeezes at n = 4096); its ~243 redraw candidates
-    // -- a window of the ciphertext's counter stream, independent of the primes -- run as the phase-synchronised
-    // k_candidates beside the chains (earliest counters first), and one light resolve launch per prime walks the
-    // window from the prime's start counter and leaves the next one.
-    //   S : bulk_0 ─(wait H_0) R_0 ─ bulk_1 ─(wait H_1) R_1 ─ ... ─ R_{np-1} ─(join A) k_encode_encrypt
-    //   C : H_0 ► H_1 ► ... (counter ranges of the window; no dependency on the chains)
-    //   A : cbd
-    // debug_flags 2048 forces it, 8192 forbids it (A/B in one process)
-    const bool lane_staged = !split && overlap && (staged_lane_mode > 0 || (debug_flags & (2048 | 32768))) &&
-                             chain_waves_per_cu <= 8 && !(debug_flags & (1 | 2 | 4 | 8 | 16 | 32 | 64 | 8192));
-    if (lane_staged)
-    {
-        if (!cand_stream)
-        {
-            SEAMD_HIP(hipStreamCreateWithFlags(&cand_stream, hipStreamNonBlocking));
-            for (auto &e : ev_cand) SEAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-        // window: after prime j a ciphertext has consumed (j + 1) bulk counters + its draws so far; mean and
-        // variance as in small_batch_plan.  ends[j] = candidates that must exist before R_j runs (mean + k sigma of
-        // the cumulative count; a ciphertext beyond it is flagged by k_resolve_light and finished by k_resolve_wave,
-        // which computes what is missing itself -- bit-identical either way).
-        uint32_t ends[kMaxPrimes], caps[kMaxPrimes];
-        {
-            double mu = 0.0, var = 0.0;
-            for (uint32_t j = 0; j < np; j++)
-            {
-                const double p = (double)(0u - dp.bound[j]) / 4294967296.0;
-                const double m = (double)hp.n * p / (1.0 - p), v = (double)hp.n * p * 1.06;
-                mu += 1.0 + m;
-                var += v;
-                uint32_t e = ((uint32_t)(mu + window_sigma * sqrt(var) + 15.0)) & ~15u;
-                if (e > spec_cap * np) e = spec_cap * np;
-                ends[j] = e;
-                // what one prime's resolve may look at: its own mean + the same margin (the window may hold more)
-                uint32_t c = ((uint32_t)(m + (window_sigma + 1.0) * sqrt(v) + 63.0)) & ~63u;
-                caps[j]    = c < 512u ? c : 512u;
-            }
-        }
-        const uint32_t W = ends[np - 1];   // row length of the window slab
-        if (B * (size_t)W > win_cap)
-        {
-            SEAMD_HIP(hipDeviceSynchronize());   // earlier calls may still read the old slab
-            if (d_win) (void)hipFree(d_win);
-            d_win = nullptr, win_cap = 0;
-            SEAMD_HIP(hipMalloc((void **)&d_win, B * (size_t)W * sizeof(uint32_t)));
-            win_cap = B * (size_t)W;
-        }
-        SEAMD_HIP(hipEventRecord(ev_fork, st));
-        SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
-        SEAMD_HIP(hipStreamWaitEvent(cand_stream, ev_fork, 0));
-        auto prime_args = [&](uint32_t j) {
-            return UniformArgs{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
-                               j,             j + 1,               np,    d_win, caps[j],
-                               0,             debug_flags,         nullptr, 0, 0, nullptr, d_nrej, ends[j], W,
-                               d_flagged};
-        };
-        // paired chains (debug flag 32768 / SE_AMD_STAGED_LANE=2): two chain waves per SIMD in phase on half the CUs
-        const bool paired = (staged_lane_mode == 2 || (debug_flags & 32768)) && B >= 512;
-        auto bulk = [&](const UniformArgs &ua) {
-            return paired ? launch_uniform_bulk_lane_sync(dp, ua, st) : launch_uniform_bulk_lane(dp, ua, st);
-        };
-        // the chain workgroups first (one per CU, 84 KiB of LDS each): the throughput kernels fill in around them
-        const size_t chain_ev = events.size();
-        stage_begin(1, st);
-        SEAMD_HIP(bulk(prime_args(0)));
-        UniformArgs uw{d_share_seeds, nullptr, nullptr, d_c1, d_rej, rej_cap, (uint32_t)B, 0, 1, np,
-                       d_win, spec_cap, 0, debug_flags, nullptr, 0, 0, nullptr, d_nrej, W, W};
-        for (uint32_t j = 0; j < np; j++)
-        {
-            const uint32_t lo = j ? ends[j - 1] : 0;
-            SEAMD_HIP(launch_uniform_candidates(uw, cand_stream, lo, ends[j] - lo));
-            SEAMD_HIP(hipEventRecord(ev_cand[j], cand_stream));
-        }
-        // the error sampler is needed last (by the fused kernel): it starts when the candidates the first resolves
-        // wait for are done, beside the last range of the window
-        // (paired chains leave half the chip to the throughput kernels: there the error sampler starts at once)
-        if (np >= 2 && !(debug_flags & 16384) && !paired) SEAMD_HIP(hipStreamWaitEvent(aux_stream, ev_cand[np - 2], 0));
-        stage_begin(0, aux_stream);
-        SEAMD_HIP(launch_sample_cbd(ca, aux_stream));
-        stage_end(aux_stream);
-        SEAMD_HIP(hipEventRecord(ev_join, aux_stream));
-        for (uint32_t j = 0; j < np; j++)
-        {
-            const UniformArgs ua = prime_args(j);
-            if (j) SEAMD_HIP(bulk(ua));
-            SEAMD_HIP(hipStreamWaitEvent(st, ev_cand[j], 0));
-            SEAMD_HIP(launch_uniform_resolve(dp, ua, st));
-        }
-        // stage 1 = the whole chain (bulk_0 .. R_{np-1}); stage 0 (cbd) is recorded on its own stream
-        if (profiling && chain_ev < events.size()) (void)hipEventRecord(events[chain_ev].stop, st);
-        SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
-        stage_begin(3, st);
-        SEAMD_HIP(launch_encode_encrypt(dp, dt, ea, kModeSym, B, st));
-        stage_end(st);
-        return 0;
-    }
     if (!split)
     {
         // Simple chain: [cbd on the aux stream || uniform] -> fused encode+encrypt.
@@ -798,7 +699,7 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         // a_j from the shareable seed, written straight into c1 (ckks_sym.c:220)
         UniformArgs ua{d_share_seeds, j ? d_ctr : nullptr, d_ctr, d_c1, d_rej, rej_cap, (uint32_t)B,
                        j,             j + 1,               np,    d_spec,      spec_cap,
-                       0,             debug_flags,         nullptr, 0, fill, nullptr, d_nrej, 0, 0,
+                       0,             debug_flags,         nullptr, 0, fill, nullptr, d_nrej,
                        staged ? d_flagged : nullptr};
         if (staged)
         {
@@ -836,21 +737,6 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
             SEAMD_HIP(launch_encode_rns(dp, dt, ea, true, B, st));
             stage_end(st);
         }
-#ifdef SEAMD_ABL_NTT_PAIR   // A/B build: two primes per k_ntt_fuse launch (N_{2k,2k+1} behind U_{2k+1}); np even
-        const bool pair_n = getenv("SE_AMD_NTT_PAIR") && np % 2 == 0;
-        if (pair_n)
-        {
-            if (j + 1 < np) SEAMD_HIP(hipEventRecord(ev_prime[j], st));   // the staged form's candidate stream waits on it too
-            if (j + 1 < np && (j & 1))
-            {
-                SEAMD_HIP(hipStreamWaitEvent(ax, ev_prime[j], 0));
-                stage_begin(5, ax);
-                SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)(j - 1) | 256, B, ax));
-                stage_end(ax);
-            }
-            continue;
-        }
-#endif
         if (j + 1 < np)
         {
             if (overlap)
@@ -869,11 +755,6 @@ int Context::encrypt_sym_impl(const float *d_values, size_t B, const uint8_t *d_
         SEAMD_HIP(hipStreamWaitEvent(st, ev_join, 0));
     }
     stage_begin(5, st);
-#ifdef SEAMD_ABL_NTT_PAIR
-    if (getenv("SE_AMD_NTT_PAIR") && np % 2 == 0)
-        SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)(np - 2) | 256, B, st));
-    else
-#endif
     SEAMD_HIP(launch_ntt_fuse(dp, dt, ea, kModeSym, (int)np - 1, B, st));
     stage_end(st);
     return 0;

@@ -75,8 +75,6 @@ struct Context
     hipEvent_t ev_cand[kMaxPrimes] = {};
     uint32_t *d_nrej = nullptr;          // [scratch_cap] rejected coefficients of the current polynomial
     uint32_t *d_flagged = nullptr;       // [1 + scratch_cap] staged forms: ciphertexts k_resolve_light left to k_resolve_wave
-    uint32_t *d_win  = nullptr;          // staged-lane form: [B][W] candidate window of every ciphertext (win_cap words)
-    size_t win_cap   = 0;
     uint8_t *d_compact  = nullptr;  // [scratch_cap] k_encode_rns -> k_ntt_fuse: plaintext b travels as one int32 row
     uint32_t *d_general = nullptr;  // [1 + general_cap] plaintexts the fast fused kernel declined (count, indices)
     size_t general_cap  = 0;
@@ -102,8 +100,6 @@ struct Context
     size_t asym_chunks = getenv("SE_AMD_ASYM_CHUNKS") ? (size_t)atoi(getenv("SE_AMD_ASYM_CHUNKS")) : 1;
     int spec_mode = -1;    // prime speculation of small symmetric calls: -1 = estimate per call, 0 never, 1 whenever planned
     int staged_mode = -1;  // pair-form staged sampler of the per-prime pipeline: -1 = by batch size, 0 never, 1 always (SE_AMD_STAGED)
-    int staged_lane_mode = 0;   // staged-lane sampler phase in front of the fused kernel (SE_AMD_STAGED_LANE; debug_flags 2048 / 8192)
-    double window_sigma = 3.0;  // its candidate window: mean + this many sigma of the cumulative draw count (SE_AMD_WINDOW_SIGMA)
     bool overlap = true;   // run independent kernels on the auxiliary stream
     int split_mode = 2;    // symmetric path: 0 = fused kernel, 1 = per-prime software pipeline
                            // (encode_rns + uniform_j || ntt_fuse_{j-1}), 2 = choose per call: the split

@@ -139,6 +139,7 @@ HostPipe::~HostPipe()
         // secret-bearing slots (seeds of e / u, the shareable seed, values, m + e) are wiped first
         wipe_slot(s);
         if (s.pte) (void)hipMemset(s.pte, 0, s.cap_pte);
+        if (s.ntt_pte) (void)hipMemset(s.ntt_pte, 0, s.cap_ntt);   // NTT(m + e) is as sensitive as m + e
         (void)hipDeviceSynchronize();
         void *ptrs[] = {s.values, s.seeds, s.share_seeds, s.c0, s.c1, s.ntt_pte, s.pte};
         for (void *p : ptrs)
@@ -186,6 +187,10 @@ int HostPipe::ensure(Context &c, size_t chunk, size_t B, bool want_ntt, bool wan
     {
         if (chunk > s.cap)
         {
+            // wipe_slot's memsets run on the null stream, which does not order against the NON-BLOCKING compute / copy
+            // streams: drain them first instead of relying on the callers having done so
+            if (compute) SEAMD_HIP(hipStreamSynchronize(compute));
+            if (copy) SEAMD_HIP(hipStreamSynchronize(copy));
             wipe_slot(s);
             values_bytes_per_ct = (n / 2) * sizeof(float);
             void **ptrs[] = {&s.values, &s.seeds, &s.share_seeds, &s.c0, &s.c1};

@@ -170,7 +170,7 @@ void lower_shutdown()
                 if (q) (void)hipFree(q);
             if (S.h_stage)
             {
-                memset(S.h_stage, 0, np * 4 * n * sizeof(uint32_t));
+                explicit_bzero(S.h_stage, np * 4 * n * sizeof(uint32_t));
                 (void)hipHostFree(S.h_stage);
             }
             if (!S.h_pte.empty()) explicit_bzero(S.h_pte.data(), S.h_pte.size() * 8);
@@ -901,6 +901,27 @@ void ckks_setup_s(const Parms *parms, uint8_t *seed, SE_PRNG *prng, ZZ *s)
 // ---- symmetric fast path (Lower::SymSpec) ----
 static const size_t kSymSpecMaxBytes = (size_t)128 << 20;   // rows of the virtual ciphertexts
 
+// The fast path keeps secret-bearing copies between the calls of ONE ciphertext: m + e and the packed key on the host
+// (the byte-for-byte guards) and on the device, the per-prime results in d_out and in the pinned staging.  They are
+// wiped as soon as the chain they belong to is over -- when its last precomputed prime has been delivered, and when
+// ckks_sym_init arms the next ciphertext (a chain abandoned half-way) -- not only at lower_shutdown.  Precondition:
+// nothing on S.st reads them any more (the caller waited for the last kernel); the device memsets are ordered on S.cp
+// behind the staging copies.
+static void sym_spec_wipe(Lower &L)
+{
+    Lower::SymSpec &S = L.sym;
+    const size_t n = L.n, np = L.c().hp.nprimes;
+    for (auto &p : S.pre) p = false;
+    if (!S.h_pte.empty()) explicit_bzero(S.h_pte.data(), S.h_pte.size() * 8);
+    if (!S.h_key.empty()) explicit_bzero(S.h_key.data(), S.h_key.size());
+    S.h_pte.clear(), S.h_key.clear();
+    if (!S.cp) return;
+    if (S.d_pte) (void)hipMemsetAsync(S.d_pte, 0, 8 * n, S.cp);
+    if (S.d_key) (void)hipMemsetAsync(S.d_key, 0, n / 4, S.cp);
+    if (S.d_out) (void)hipMemsetAsync(S.d_out, 0, np * 3 * n * sizeof(uint32_t), S.cp);
+    if (S.h_stage) explicit_bzero(S.h_stage, np * 4 * n * sizeof(uint32_t));
+}
+
 // windows of the start counters of primes 1 .. np-1 (the estimate of Context::small_batch_plan), as many primes as the
 // row budget allows; launches the samplers on S.st.  The caller holds g_mu.
 static void sym_spec_arm(Lower &L, const Parms *parms, const SE_PRNG *shareable)
@@ -930,6 +951,8 @@ static void sym_spec_arm(Lower &L, const Parms *parms, const SE_PRNG *shareable)
     {
         LOWER_HIP(hipStreamSynchronize(S.st));   // an earlier speculation nobody consumed
         LOWER_HIP(hipStreamSynchronize(S.cp));
+        sym_spec_wipe(L);                        // ... and what an abandoned chain left behind
+        LOWER_HIP(hipStreamSynchronize(S.cp));   // (its memsets run on S.cp; the uploads below do not order against it)
     }
     // plan
     double mu = 0.0, var = 0.0;
@@ -959,16 +982,17 @@ static void sym_spec_arm(Lower &L, const Parms *parms, const SE_PRNG *shareable)
         LOWER_HIP(hipMalloc((void **)&S.d_rows, (size_t)total * n * sizeof(uint32_t)));
         LOWER_HIP(hipMalloc((void **)&S.d_meta, (size_t)total * 88));
         S.cap      = total;
-        S.d_seeds  = S.d_meta;
-        S.d_ctr    = (uint64_t *)(S.d_meta + (size_t)total * 64);
-        S.d_ctrout = S.d_ctr + total;
-        S.d_prime  = (uint8_t *)(S.d_ctrout + total);
     }
+    // carved for THIS plan's `total` (<= cap), so that one upload of total x 88 bytes covers it
+    S.d_seeds  = S.d_meta;
+    S.d_ctr    = (uint64_t *)(S.d_meta + (size_t)total * 64);
+    S.d_ctrout = S.d_ctr + total;
+    S.d_prime  = (uint8_t *)(S.d_ctrout + total);
     if (c.ensure_scratch(1, (size_t)1 + total) != 0) die("GPU scratch");
     // seeds | counters | (end counters) | primes of the virtual ciphertexts: one upload
-    std::vector<uint8_t> meta((size_t)S.cap * 88, 0);
-    uint64_t *hc = (uint64_t *)(meta.data() + (size_t)S.cap * 64);
-    uint8_t *hp  = meta.data() + (size_t)S.cap * 80;
+    std::vector<uint8_t> meta((size_t)total * 88, 0);
+    uint64_t *hc = (uint64_t *)(meta.data() + (size_t)total * 64);
+    uint8_t *hp  = meta.data() + (size_t)total * 80;
     for (uint32_t j = 0; j < covered; j++)
         for (uint32_t g = 0; g < S.count[j]; g++)
         {
@@ -1115,6 +1139,9 @@ void ckks_encode_encrypt_sym(const Parms *parms, const int64_t *conj_vals_int, c
         const uint64_t before   = shareable_prng->counter;
         shareable_prng->counter = S.pre_end[j];
         after_draws(shareable_prng, before);
+        // the last precomputed prime of the chain has been delivered (its kernel and copies are done, and S.st / S.cp
+        // are in order, so every earlier prime's are too): nothing of this ciphertext stays behind
+        if (S.step_of_prime(j) + 1 == S.nprimes) sym_spec_wipe(L);
         return;
     }
     // c1 = a <- U (ckks_sym.c:220); the counter moves exactly as the reference's rejection loop

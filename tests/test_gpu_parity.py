@@ -319,51 +319,6 @@ def test_staged_sampler_pipeline(env, shape, B):
         ctx.close()
 
 
-@pytest.mark.parametrize("flags", [2048, 32768], ids=["lone_chains", "paired_chains"])
-@pytest.mark.parametrize("shape,B", [((1024, 1), 70), ((4096, 3), 131), ((4096, 3), 1500), ((2048, 1), 513)],
-                         ids=lambda v: str(v))
-def test_staged_lane_sampler_phase(env, shape, B, flags):
-    """The staged-LANE form of the symmetric sampler phase (round 5: k_bulk_lane -- one ciphertext per lane, only
-    the bulk squeeze in the chain --, the redraw candidates of all primes as ONE window of the ciphertext's counter
-    stream computed by the phase-synchronised k_candidates beside the chains, one light resolve per prime walking
-    the window from the prime's start counter; forced with debug flag 2048 in front of the fused kernel) against the
-    oracle: ragged batches (idle lanes, partial workgroups, a last candidate workgroup with few live lanes), a window
-    that is far too short (every ciphertext finished by k_resolve_wave with candidates it computes itself), a reject
-    list that is too short (marker scan), repeated calls on the same scratch.  Flag 32768: the chains as PAIRED waves
-    (k_bulk_lane_sync: two chain waves per SIMD squeezing with the phase-synchronised full permutation; B >= 512, else
-    the lone form serves the call) -- a last workgroup with a few live waves, whole waves that end before the first
-    barrier."""
-    from oracle.pyoracle import Oracle
-    torch = env["torch"]
-    n, npr = shape
-    o = Oracle(n, npr)
-    sk = V.secret_key(n, seed=23)
-    vals = V.bench_values(B, n, first=1700)
-    ss, sd = V.bench_seeds(B, first=1700)
-    from oracle import pyoracle
-    ok, e0, e1 = o.encrypt_sym_batch(vals, ss, sd, sk, nthreads=pyoracle.host_threads())
-    assert ok
-    for spec_cap, rej_cap in ((None, None), (8, None), (None, 5), (1, 0)):
-        ctx = env["pkg"].Context(n, npr)
-        ctx.set_secret_key(sk)
-        ctx.set_pipeline(1, 0)
-        ctx.set_debug_flags(flags)
-        if spec_cap is not None:
-            ctx.set_speculation_capacity(spec_cap)
-        if rej_cap is not None:
-            ctx.set_reject_list_capacity(rej_cap)
-        for rep in range(2):
-            c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
-            c1 = torch.zeros_like(c0)
-            st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
-            ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, status=st)
-            torch.cuda.synchronize()
-            assert bool(st.all())
-            assert np.array_equal(host_u32(c1), e1), (spec_cap, rej_cap, rep)
-            assert np.array_equal(host_u32(c0), e0), (spec_cap, rej_cap, rep)
-        ctx.close()
-
-
 def test_sample_uniform_speculation_shortfall_path(env):
     """Helper waves precompute spec_cap redraw candidates per ciphertext; when a ciphertext needs
     more, the rest goes through the pooled loop.  Forced here with tiny capacities."""
@@ -1174,10 +1129,10 @@ def _compare_all_with_oracle(c0, c1, oracle_chunk, B, chunk=4096):
         del e1
 
 
-@pytest.mark.parametrize("form", ["dispatch", "lane_chain", "staged_lane", "paired_chains"])
+@pytest.mark.parametrize("form", ["dispatch"])
 def test_full_size_properties_config2(env, form):
-    """(form: the sampler phase the library's dispatch picks at this batch; forced to the one-launch lane chain
-    (debug flag 8192); forced to the staged-lane form of round 5 (2048) -- every ciphertext through each.)
+    """(form: what the library's dispatch picks at this batch -- one-launch lane chains || CBD, then the fused kernel;
+    SE_TEST_C2_FORMS=split adds the per-prime software pipeline forced at the same batch.)
     BASELINE config 2 shape (n=4096, 3 primes) at a large batch: (a) the reference's own
     round-trip criterion c0 + c1*NTT(s) == NTT(m+e) exactly (ckks_tests_common.c:206) evaluated
     on the GPU outputs for EVERY ciphertext; (b) oracle spot checks on scattered records;
@@ -1189,7 +1144,8 @@ def test_full_size_properties_config2(env, form):
     n, npr = 4096, 3
     B = int(os.environ.get("SE_TEST_FULL_B", "65536"))   # BASELINE config 2 batch
     ctx = env["pkg"].Context(n, npr)
-    ctx.set_debug_flags({"dispatch": 0, "lane_chain": 8192, "staged_lane": 2048, "paired_chains": 32768}[form])
+    if form == "split_pipeline" or os.environ.get("SE_TEST_C2_FORMS") == "split":
+        ctx.set_pipeline(True, True)
     sk = V.secret_key(n)
     ctx.set_secret_key(sk)
     o = Oracle(n, npr)
@@ -1906,9 +1862,9 @@ for n, npr in ((1024, 1), (4096, 3)):
         vals = dt(V.bench_values(B, n, first=11))
         ss, sd = V.bench_seeds(B, first=11)
         c0 = torch.zeros((B, npr, n), dtype=torch.int32, device=dev); c1 = torch.zeros_like(c0)
-        # k_candidates through both staged dispatches (pair form: per-prime rows; lane form: window ranges), tiny
-        # capacities so that B * spec_cap is nowhere near a multiple of 512 and k_resolve_wave walks a flagged list
-        for flags, split in ((512, 1), (2048, 0)):
+        # k_candidates through the staged dispatch (pair form: per-prime rows), tiny capacities so that
+        # B * spec_cap is nowhere near a multiple of 512 and k_resolve_wave walks a flagged list
+        for flags, split in ((512, 1),):
             for cap in (None, 1, 7):
                 step("staged flags=%d n=%d B=%d cap=%s" % (flags, n, B, cap))
                 c2 = pkg.Context(n, npr); c2.set_secret_key(sk); c2.set_pipeline(1, split); c2.set_debug_flags(flags)

@@ -106,33 +106,6 @@ def test_header_is_what_the_generator_writes():
     assert peak <= 120        # v8 .. : leaves a 128-VGPR kernel room for its own values
 
 
-def test_full_permutation_block_squeezes_shake256():
-    """keccak_f1600_sync (state in / state out, the squeeze step of the paired chain kernel k_bulk_lane_sync): absorb
-    seed || le64(ctr) || pad as keccak.cuh's prng_absorb does, run the block twice: the rate lanes after each run are
-    bytes [0, 136) and [136, 272) of SHAKE256(seed || le64(ctr)); 96 barriers per run."""
-    text = open(HEADER).read()
-    base = int(re.search(r"state pinned to v(\d+)\.\.", text).group(1))
-    lines = asm_of(text, "keccak_f1600_sync")
-    rng = np.random.default_rng(20261001)
-    for case in range(2):
-        seed = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
-        ctr = [7, 2**63 + 99][case]
-        msg = seed + struct.pack("<Q", ctr)
-        block = bytearray(200)
-        block[:72] = msg
-        block[72] ^= 0x1F
-        block[135] ^= 0x80
-        st = list(struct.unpack("<50I", bytes(block)))
-        want = hashlib.shake_256(msg).digest(272)
-        regs = {base + k: st[k] for k in range(50)}
-        for run in range(2):
-            regs, barriers = run_asm(lines, regs)
-            assert barriers == 96
-            got = struct.pack("<34I", *[regs[base + k] for k in range(34)])
-            assert got == want[136 * run:136 * (run + 1)], (case, run)
-            regs = {base + k: regs[base + k] for k in range(50)}
-
-
 def test_generated_blocks_compute_shake256():
     text = open(HEADER).read()
     base = int(re.search(r"state pinned to v(\d+)\.\.", text).group(1))
@@ -172,7 +145,7 @@ def test_constraint_lists_cover_every_register_the_blocks_write():
     the clobber list; every register it READS before writing it is a pinned operand (or the table pointer); scc is
     clobbered; nothing outside v8..v77 / s16..s30 is touched."""
     text = open(HEADER).read()
-    for func in ("keccak_fresh96_sync", "keccak_fresh4_sync", "keccak_f1600_sync"):
+    for func in ("keccak_fresh96_sync", "keccak_fresh4_sync"):
         lines, outs, ins, clob = _asm_parts(text, func)
         pinned = {int(x) for x in re.findall(r"\"\+\{v(\d+)\}\"", outs)}          # in/out: readable from the start
         outonly = {int(x) for x in re.findall(r"\"=&\{v(\d+)\}\"", outs)}       # early-clobber outputs: write first
@@ -307,53 +280,3 @@ def test_compiled_sync_kernels_keep_the_barrier_contract():
     for name in SYNC_KERNELS:
         m = re.search(r"\.amdhsa_kernel _ZN5seamd\d+" + name + r"E\w*\n(?:.*\n){0,6}?\s+\.amdhsa_private_segment_fixed_size (\d+)", meta)
         assert m and int(m.group(1)) == 0, (name, m and m.group(1))
-
-
-def test_compiled_paired_chain_kernel_keeps_the_barrier_contract():
-    """k_bulk_lane_sync (two chain waves per SIMD squeezing with keccak_f1600_sync; behind SE_AMD_STAGED_LANE=2): the
-    block sits in the step loop and once more for the tail words, so every live wave runs it FULL_STEPS + 1 times -- IF
-    the only way around a block is the whole-wave exit in front of the loop.  On the ISA of every instantiation:
-    exactly two asm regions with barriers (loop body, tail); a branch in front of the first that goes past it ends the
-    wave; between the two blocks control either stays in the loop or arrives right in front of the second block (the
-    loop exit) -- nothing jumps over the second block; behind the second block nothing branches back; no scratch."""
-    isa = _samplers_isa()
-    header = open(HEADER).read()
-    static = sum(1 for ln in _asm_parts(header, "keccak_f1600_sync")[0] if ln.strip() == "s_barrier")
-    branch_re = re.compile(r"\s+(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)")
-    starts = [i for i, ln in enumerate(isa) if re.match(r"^_ZN5seamd16k_bulk_lane_syncILi1[0-4]ELb[01]EE\w*:", ln)]
-    assert len(starts) == 10
-    for start in starts:
-        end = next(i for i in range(start, len(isa)) if isa[i].startswith(".Lfunc_end"))
-        body, name = isa[start:end], isa[start].split(":")[0]
-        app = [i for i, ln in enumerate(body) if ln.strip().startswith(";;#ASMSTART")]
-        noapp = [i for i, ln in enumerate(body) if ln.strip().startswith(";;#ASMEND")]
-        blocks = [(a, b) for a, b in zip(app, noapp) if any(ln.strip().startswith("s_barrier") for ln in body[a:b])]
-        assert len(blocks) == 2, (name, len(blocks))
-        for a, b in blocks:
-            assert sum(1 for ln in body[a:b] if ln.strip().startswith("s_barrier")) == static, name
-        (a1, b1), (a2, b2) = blocks
-        assert not any(ln.strip().startswith("s_barrier") for ln in body[:a1] + body[b1:a2] + body[b2:]), name
-        labels = {ln.split(":")[0]: i for i, ln in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", ln)}
-        endpgm = [i for i, ln in enumerate(body) if "s_endpgm" in ln]
-        assert len(endpgm) == 1, name
-        for i, ln in enumerate(body):
-            m = branch_re.match(ln)
-            if not m:
-                continue
-            tgt = labels[m.group(2)]
-            if i < a1:                                   # in front of the loop's block (the loop latch is laid out here)
-                if b1 <= tgt <= a2:
-                    continue                             # the loop exit: arrives in front of the tail block
-                if tgt > a1:
-                    j = tgt
-                    while "s_endpgm" not in body[j]:     # the whole-wave exit: straight to the end
-                        assert not branch_re.match(body[j]) and not body[j].strip().startswith("s_barrier"), (name, ln)
-                        j += 1
-                    assert tgt >= b2, (name, "jump into the loop past its block", ln.strip())
-            elif b1 <= i < a2:                           # loop body behind the block: stay in the loop or reach block 2
-                assert tgt <= a2, (name, "a path around the tail block", ln.strip())
-                assert not (a1 < tgt < b1), (name, "jump into the block", ln.strip())
-            elif i >= b2:                                # behind the tail block
-                assert tgt >= b2, (name, "branch back over a block", ln.strip())
-        text = "\n".join(body)
-        assert "scratch_" not in text, name

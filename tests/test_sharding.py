@@ -106,6 +106,20 @@ def test_bench_contract_constants():
                 '"gather_verified"', '"per_source_GB/s"', '"per_thread_value"'):
         assert key in src, key
     assert len(bench.kernel_source_hash()) == 16
+    # the further configurations as the LAST key of the line, whole inside the last 600 bytes of stdout (the driver's
+    # record keeps the tail of stdout verbatim: VERDICT r5 item 4)
+    import json
+    fake = [{"value": 7734567.891, "ms_per_step": 8.47312345, "roofline": {"frac": 0.10312345, "dominant_kernel":
+             {"ms_per_step": 4.7312345}}, "cpu_baseline": {"value": 1.0}} for _ in range(4)]
+    fake[3] = {"config": {"workload": "x"}, "error": "RuntimeError('boom " + "x" * 200 + "')"}
+    line = {"metric": "m", "value": 1.0, "other_configs": fake}
+    line["other_configs_summary"] = bench.configs_summary(["c3", "c4", "c5", "c1"], fake)
+    text = json.dumps(line)
+    tail = text[-600:]
+    assert list(line)[-1] == "other_configs_summary" and '"other_configs_summary": {"c3"' in tail
+    assert json.loads(tail[tail.index('{"c3"'):-1])["c5"] == {"value": 7735000.0, "ms_per_step": 8.473, "frac": 0.1031,
+                                                              "dominant_ms": 4.731}
+    assert "line.pop(\"other_configs_summary\", None)" in src      # re-appended after every further config: stays last
     # optional workloads beyond BASELINE.json carry the same per-unit byte formulas
     assert wl["x1"][:3] == (16384, 6, "asym") and wl["x2"][:3] == (8192, 6, "sym")
     # the opcode-weighted VALU bound: profiles/valu_mix.json is stamped with the kernel sources it was built from and

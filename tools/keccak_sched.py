@@ -403,7 +403,7 @@ def _segment(rounds, zero_in=(), need_out=None, bar=4):
     return emit_asm(order, reg, PROD_BASE, SRC, None, bar), peak, len(order)
 
 
-def product_header(full=True):
+def product_header(full=False):
     """seal-embedded_amd/csrc/kernels/keccak_sync.cuh: the permutation of a freshly absorbed PRNG message (keccak.cuh,
     prng_absorb) whose caller consumes the first 96 bytes, for kernels in which SEVERAL WAVES OF ONE WORKGROUP SHARE A
     SIMD: whole-phase instruction order and an s_barrier at every change of issue class."""
@@ -438,8 +438,9 @@ def product_header(full=True):
     clob_full = ", ".join(f'"v{B + k}"' for k in range(50, pm))
     null_asm = "\\n\\t".join([f"s_movk_i32 s30, {4 * 24}", "1:", "s_barrier", "s_sub_u32 s30, s30, 1", "s_cmp_lg_u32 s30, 0",
                               "s_cbranch_scc1 1b"])
-    # also the state-in / state-out permutation (round 5: the paired chain kernel k_bulk_lane_sync squeezes with it) and
-    # the barrier-only form (the lockstep sampler experiment of round 4, profiles/r04_ab_lockstep.log)
+    # --full: also the state-in / state-out permutation (round 5: the paired chain kernel k_bulk_lane_sync squeezed with it,
+    # experiments/r05_staged_lane_paired_chains.patch) and the barrier-only form (the lockstep sampler experiment of round
+    # 4, profiles/r04_ab_lockstep.log); the product header carries neither
     extras = f'''// The full permutation, state in and out (lane i = s[2 i] (lo), s[2 i + 1] (hi)): the squeeze step of a sponge whose
 // state stays in registers (12 iterations of the two-round body, {4 * 24} barriers, {12 * nm} VALU instructions).
 __device__ __forceinline__ void keccak_f1600_sync(uint32_t (&s)[50], const uint32_t *rc)
@@ -510,7 +511,7 @@ __device__ __forceinline__ void keccak_fresh4_sync(uint32_t (&w)[18], const uint
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     if "--product" in sys.argv:
-        text, total, peak = product_header("--no-full" not in sys.argv)
+        text, total, peak = product_header("--full" in sys.argv)
         path = os.path.join(here, "..", "seal-embedded_amd", "csrc", "kernels", "keccak_sync.cuh")
         with open(path, "w") as f:
             f.write(text)
