@@ -359,8 +359,9 @@ int se_amd_set_host_chunk(se_amd_ctx *ctx, size_t ciphertexts);
 /* Pre-allocate the internal scratch for batches of up to B plaintexts (keeps hipMalloc out of
  * the first timed call). */
 int se_amd_reserve(se_amd_ctx *ctx, size_t B);
-/* Test / A/B hook: which FORM of the samplers and pipelines a call takes.  Bits 1, 2, 4 are timing ablations of the
- * uniform sampler that make outputs WRONG (tools/ablate.py).  Every other bit only selects among bit-identical forms:
+/* Test / A/B hook: which FORM of the samplers and pipelines a call takes.  Every bit only selects among bit-identical
+ * forms (the timing ablations of rounds 1-5 that produced WRONG outputs -- bits 1, 2, 4 -- are gone: no setting of this
+ * word changes a result):
  *   8 no helper waves, 16 helper waves without speculation, 32 / 64 force the lane / wave form of the chain kernels,
  *   128 early encoder at n = 16384, 256 speculation windows of one guess (forces the miss path), 512 / 1024 force /
  *   forbid the pair-form staged sampler, 4096 ternary window of blocks + 2 counters (forces the fallback).

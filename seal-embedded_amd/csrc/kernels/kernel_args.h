@@ -38,8 +38,8 @@ struct UniformArgs
     uint32_t *spec;        // [B][spec_cap] scratch: candidates precomputed by helper waves
     uint32_t spec_cap;
     uint32_t master_waves; // waves of a workgroup that own ciphertexts (the rest are redraw helpers)
-    uint32_t debug_flags;  // ablation (timing experiments only): 2 = no phase 2 (wrong results);
-                           // 8 = no helper waves, 16 = helpers without speculation (results stay correct)
+    uint32_t debug_flags;  // form selection for tests / A/B runs (results are bit-identical): 8 = no helper waves,
+                           // 16 = helpers without speculation, 32 / 64 = always the lane / the wave form
     const uint32_t *only_from;  // optional [B]: ciphertext b takes part only if only_from[b] != 0 and
                                 // prime_lo >= only_from[b] (redo of speculation misses)
     uint32_t out_prime_base;  // output row of prime j is (b * out_primes + j - out_prime_base): lets a

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
         uint32_t nrej = 0;
         const uint64_t bulk_ctr = ctr;   // the 4n-byte block; redraw candidates follow at ctr + 1 ..
         ctr++;
-        const bool speculate = wg_pool && A.spec && !(A.debug_flags & 2);
+        const bool speculate = wg_pool && A.spec;
         if (speculate)
         {
             // Helper waves know every candidate counter up front (the bulk block consumes exactly
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
         // on K0 (a candidate is only *consumed* when the lane needs one, in counter order).
         uint32_t k0 = 0, cpos = 0;
         uint32_t *lds_c0 = reinterpret_cast<uint32_t *>(pin_lds + 1024);  // [k0][blockDim.x]
-        if (!wg_pool && !(A.debug_flags & 2))
+        if (!wg_pool)
         {
             const float mean = (float)N * ((float)(0u - bound) * (1.0f / 4294967296.0f));
             const float lo   = mean - 1.5f * sqrtf(mean);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
         // are dealt round-robin over the R needy lanes (slot s -> needy lane s % R, counter offset
         // s / R) and every needy lane then consumes its candidates in counter order.  The wave
         // finishes in ~ceil(total draws / 64) rounds instead of max-over-lanes draws.
-        uint32_t need    = (A.debug_flags & 2) ? 0u : nrej;
+        uint32_t need    = nrej;
         uint32_t k       = 0;  // rejected coefficients resolved so far
         uint32_t scanpos = 0;  // list-overflow path: next index to scan for a marker
 
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void k_resolve_light(DevParams P, UniformArgs 
     if (b >= A.B) return;   // wave-uniform
     const uint32_t j    = A.prime_lo;
     const uint32_t nrej = A.nrej[b];
-    uint32_t need       = (A.debug_flags & 2) ? 0u : nrej;
+    uint32_t need       = nrej;
     const uint64_t c0   = A.ctr_in ? A.ctr_in[b] : 0;
     uint64_t ctr        = c0 + 1;   // the bulk block took one counter
     uint32_t row_len;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void k_resolve_wave(DevParams P, UniformArgs A
         // after k_resolve_light: only the ciphertexts it flagged (top bit of the count) are left
         const uint32_t raw = A.nrej[b];
         if (A.master_waves == 1u && !(raw & 0x80000000u)) continue;
-        const uint32_t need = (A.debug_flags & 2) ? 0u : (raw & 0x7FFFFFFFu);
+        const uint32_t need = raw & 0x7FFFFFFFu;
         if (need > 0)
         {
             uint32_t seed[16];
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_sample_uniform_wave(DevParams P, Unifor
         __threadfence_block();
 
         // ---- redraws: 64 candidates block(ctr + lane)[0:4] per round -------------------------------
-        wave_redraws<N>(q, crh, bound, mypoly, mylist, A.rej_cap, (A.debug_flags & 2) ? 0u : nrej, seed, ctr, nullptr,
+        wave_redraws<N>(q, crh, bound, mypoly, mylist, A.rej_cap, nrej, seed, ctr, nullptr,
                         0u, lane);
         __builtin_amdgcn_s_waitcnt(0);
     }
@@ -1358,8 +1358,7 @@ hipError_t launch_sample_uniform(const DevParams &P, const UniformArgs &A0, hipS
     if (A0.B == 0) return hipSuccess;
     // A handful of chains: one wave per ciphertext (2.2-2.7x shorter chains up to one wave per SIMD, break-even
     // near 4 per SIMD -- tools/ubench5).  debug_flags 32 / 64 force the lane / the wave form (tests).
-    if (((A0.B <= uniform_wave_limit(P.num_cus) && !(A0.debug_flags & 32)) || (A0.debug_flags & 64)) &&
-        !(A0.debug_flags & (1 | 4)))
+    if ((A0.B <= uniform_wave_limit(P.num_cus) && !(A0.debug_flags & 32)) || (A0.debug_flags & 64))
     {
         switch (P.logn)
         {

@@ -19,6 +19,5 @@ sq) W=${PMC_WL:-c2}; i=0; for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
 hostrate) ( timeout 600 python tools/host_rate.py ) > gpurun_out/host_rate.log 2>&1; cat gpurun_out/host_rate.log;;
 ablate3) ( timeout 900 python tools/ablate3.py ) > gpurun_out/ablate3.log 2>&1; cat gpurun_out/ablate3.log;;
 ablate2) ( timeout 600 python tools/ablate2.py ) > gpurun_out/ablate2.log 2>&1; cat gpurun_out/ablate2.log;;
-ablate) ( timeout 600 python tools/ablate.py ) > gpurun_out/ablate.log 2>&1; cat gpurun_out/ablate.log;;
 esac
 done

@@ -25,7 +25,7 @@ if mode == "sym":
     ctx.set_secret_key(sk)
 elif mode == "asym":
     ctx.set_public_key(*ctx.gen_public_key(sk, bytes(64), bytes(range(64))))
-ctx.set_debug_flags(int(os.environ.get("SE_PMC_FLAGS", "0")))   # e.g. 2 = no redraw phase (traffic of the bulk alone)
+ctx.set_debug_flags(int(os.environ.get("SE_PMC_FLAGS", "0")))   # form selection (include/seal_embedded_amd.h)
 vals = bench.bench_values_device(B, n, dev)
 ss_np, sd_np = V.bench_seeds(B) if mode != "encode" else (None, None)
 ss = torch.from_numpy(ss_np).to(dev) if ss_np is not None else None
