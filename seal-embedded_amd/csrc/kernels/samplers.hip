@@ -197,8 +197,7 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
             // with 64 lanes some lane rejects at ~70 % of the word positions, so a per-word
             // `if (reject)` costs its mask/branch scaffolding 34 times per squeeze step.  Here each
             // word is reduce + compare + select-marker + shift the reject bit into a per-lane
-            // mask; the masks are turned into reject-list entries once per step (a loop of
-            // max-over-lanes popcount, ~3 iterations).
+            // mask; the masks are turned into patches / reject-list entries once per GROUP of steps (flush_group).
             // (r4: every accepted word is below 4q, see reduce_sample; a rejected word's value is not used)
             auto word = [&](auto r4, uint32_t x, uint32_t &mask) -> uint32_t {
                 const bool rej   = x >= bound;
@@ -207,40 +206,49 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
                 return rej ? kRejMarker : r;
             };
             const bool red4 = !LANE_PRIME && (uint64_t)bound <= 4ull * q;   // uniform per prime
-            // mask holds `count` words, word w of the step at bit (count - 1 - w); entries are
-            // appended in ascending position order
-            auto flush = [&](uint32_t mask, uint32_t count, uint32_t first_pos) {
-                while (__any(mask != 0))
+            // The reject bits of kFlushGroup = 3 consecutive squeeze steps (102 words) are collected in a 128-bit string
+            // (mh : ml), the group's first word at the top of its `nbits` valid bits, and turned into patches / list
+            // entries ONCE per group: the loop below runs max-over-lanes(rejects of the lane) times, ~5.7 per group of 102
+            // words against 3 x (3.1 + 0.9) when every step flushed its 32- and its 2-bit mask separately (round 6:
+            // the bookkeeping was 5 % of the chain, profiles/r06_ab_emit_diet.log).  Positions are handled in ascending
+            // order; a patch lands at most three steps (~30 us) behind the store of its marker.
+            // `cnext` is the lane's next phase-0 candidate, fetched from LDS one consumption ahead so that the loop
+            // never waits for the read.
+            uint64_t mh = 0, ml = 0;
+            uint32_t cnext = k0 ? lds_c0[threadIdx.x] : 0u;
+            // One candidate per pass and lane, no inner loop (a lone wave pays for every scalar / branch instruction of
+            // nested divergent control flow): a lane whose candidate is itself rejected (1.9 %) keeps its bit and
+            // takes the next candidate in the next pass.  The patch and the list append are ONE predicated store.
+            auto flush_group = [&](uint32_t nbits, uint32_t first_pos) {
+                while (__any((mh | ml) != 0))
                 {
-                    if (mask != 0)
+                    if ((mh | ml) != 0)
                     {
-                        const uint32_t p   = (uint32_t)__clz((int)mask);
-                        const uint32_t pos = first_pos + (p - (32u - count));
-                        mask &= ~(0x80000000u >> p);
-                        // next accepted phase-0 candidate, if any is left: patch in place
-                        bool patched = false;
-                        while (cpos < k0)
+                        const uint32_t c   = mh ? (uint32_t)__clzll((long long)mh) : 64u + (uint32_t)__clzll((long long)ml);
+                        const uint32_t pos = first_pos + (c - (128u - nbits));
+                        const bool have    = cpos < k0;          // a phase-0 candidate is left
+                        const uint32_t x   = cnext;
+                        const bool acc     = have && x < bound;  // ... and accepted: patch in place
+                        const bool listed  = !have;              // none left: the position goes to the reject list
+                        cpos += have ? 1u : 0u;
+                        ctr += have ? 1u : 0u;
+                        cnext = lds_c0[min(cpos, k0 - 1u) * blockDim.x + threadIdx.x];   // (k0 = 0: never consumed)
+                        uint32_t *dst      = acc ? mypoly + pos : mylist + nrej;
+                        const uint32_t val = acc ? barrett32(x, q, crh) : pos;
+                        if (acc || (listed && nrej < A.rej_cap)) *dst = val;
+                        nrej += listed ? 1u : 0u;
+                        if (acc || listed)
                         {
-                            const uint32_t x = lds_c0[cpos * blockDim.x + threadIdx.x];
-                            cpos++;
-                            ctr++;
-                            if (x < bound)
-                            {
-                                mypoly[pos] = barrett32(x, q, crh);
-                                patched     = true;
-                                break;
-                            }
-                        }
-                        if (!patched)
-                        {
-                            if (nrej < A.rej_cap) mylist[nrej] = pos;
-                            nrej++;
+                            const uint64_t bit = 0x8000000000000000ull >> (c & 63u);
+                            mh &= c < 64u ? ~bit : ~0ull;
+                            ml &= c < 64u ? ~0ull : ~bit;
                         }
                     }
                 }
             };
+            constexpr uint32_t kFlushGroup = 3;
 
-            uint32_t idx = 0;
+            uint32_t idx = 0, gbase = 0, gsteps = 0;   // first word / steps of the group being collected
             for (int step = 0; step < FULL_STEPS; step++)
             {
                 keccak_f1600(st);
@@ -259,16 +267,21 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
                     emit(std::true_type{});
                 else
                     emit(std::false_type{});
-                if (__any((m0 | m1) != 0))
-                {
-                    flush(m0, 32, idx);
-                    flush(m1, 2, idx + 32);
-                }
+                // (mh : ml) <<= 34, the step's 34 bits appended (word 0 of the step first)
+                mh = (mh << 34) | (ml >> 30);
+                ml = (ml << 34) | ((uint64_t)m0 << 2) | (uint64_t)m1;
                 idx += 34;
+                if (++gsteps == kFlushGroup)
+                {
+                    flush_group(34u * kFlushGroup, gbase);
+                    gsteps = 0;
+                    gbase  = idx;
+                }
             }
             if constexpr (TAIL_WORDS > 0)
             {
                 static_assert(TAIL_WORDS <= 32 && TAIL_WORDS % 2 == 0, "tail fits one mask");
+                static_assert(34 * (kFlushGroup - 1) + TAIL_WORDS <= 128, "an unfinished group and the tail share the string");
                 keccak_f1600(st);
                 uint32_t m0 = 0;
 #pragma unroll
@@ -278,8 +291,12 @@ __global__ __launch_bounds__(MAXT) void k_sample_uniform(DevParams P, UniformArg
                     uint32_t w1 = word(std::false_type{}, st.hi[i], m0);
                     *reinterpret_cast<uint2 *>(mypoly + idx + 2 * i) = make_uint2(w0, w1);
                 }
-                flush(m0, TAIL_WORDS, idx);
+                mh = (mh << TAIL_WORDS) | (ml >> (64 - TAIL_WORDS));
+                ml = (ml << TAIL_WORDS) | (uint64_t)m0;
+                flush_group(34u * gsteps + (uint32_t)TAIL_WORDS, gbase);
             }
+            else if (gsteps)
+                flush_group(34u * gsteps, gbase);
         }
         // bulk stores (and list entries) must have landed before phase 2 patches / reads them
         __builtin_amdgcn_s_waitcnt(0);
