@@ -51,10 +51,11 @@ PY
 )
 N=${FMG_GPUS:-$NDEV}; [ "$N" -gt 8 ] && N=8
 say "distinct PCI devices visible: $NDEV (using $N)"
-if [ "$NDEV" -lt 2 ]; then
-  say "VERDICT: one physical device -- nothing to learn here (compute partition: $(rocm-smi --showcomputepartition 2>/dev/null | grep -i partition | head -1))"
+if [ "$NDEV" -lt 2 ] && [ -z "$FMG_FORCE" ]; then
+  say "VERDICT: one physical device -- nothing to learn here (compute partition: $(rocm-smi --showcomputepartition 2>/dev/null | grep -i partition | head -1)); FMG_FORCE=1 runs the steps anyway (a dry run of this script: every rank lands on the one device)"
   exit 0
 fi
+[ "$NDEV" -lt 2 ] && N=${FMG_GPUS:-2}    # dry run on one device: two ranks share it
 
 # 1. topology: are the devices xGMI peers at all?
 step topo 60 rocm-smi --showtopo

@@ -60,9 +60,8 @@ while time.time() - t0 < budget:
     ov, sp = rng.choice([(1, 2), (1, 2), (0, 0), (1, 0), (0, 1), (1, 1)])
     ctx.set_pipeline(ov, sp)
     ctx.set_reject_list_capacity(rng.choice([0, 0, 0, 3, 40]) or max(256, n // 16))
-    # sampler forms: automatic / lane per ciphertext / staged (lane pairs + candidate kernel) / wave per ciphertext /
-    # (round 5) staged-lane window form in front of the fused kernel, lone and paired chains
-    form = rng.choice([0, 0, 32, 512, 64, 2048, 32768])
+    # sampler forms: automatic / lane per ciphertext / staged (lane pairs + candidate kernel) / wave per ciphertext
+    form = rng.choice([0, 0, 32, 512, 64])
     ctx.set_debug_flags(form)
     desc = f"seed={master} case={cases} n={n} np={npr} B={B} mode={mode} vals={kind} pipe=({ov},{sp}) form={form} case_seed={case_seed}"
     if mode == "stage":
