@@ -120,9 +120,13 @@ struct Lower
         uint64_t pre_start[seamd::kMaxPrimes] = {}, pre_end[seamd::kMaxPrimes] = {};
         std::vector<int64_t> h_pte;                      // the plaintext d_pte holds (empty: none)
         std::vector<uint8_t> h_key;                      // the packed key d_key holds
-        int64_t *d_pte  = nullptr;                       // [n]
-        uint8_t *d_key  = nullptr;                       // [n/4]
-        uint32_t *d_out = nullptr;                       // [np][3][n]: c0 | ntt_pte | s_save
+        // one slab (one memset wipes it): d_pte [n] int64 | d_out [np][3][n]: c0 | ntt_pte | s_save | d_key [n/4]
+        uint8_t *d_slab = nullptr;
+        size_t slab_bytes = 0;
+        int64_t *d_pte  = nullptr;
+        uint8_t *d_key  = nullptr;
+        uint32_t *d_out = nullptr;
+        bool dirty = false;                              // secret-bearing copies exist since the last wipe
         uint32_t *h_stage = nullptr;                     // pinned [np][4][n]: a | c0 | ntt_pte | s_save
     } sym;
 };
@@ -161,11 +165,9 @@ void lower_shutdown()
             const size_t n = L->n, np = L->c().hp.nprimes;
             if (S.d_rows) (void)hipMemset(S.d_rows, 0, S.cap * n * sizeof(uint32_t));
             if (S.d_meta) (void)hipMemset(S.d_meta, 0, S.cap * 88);
-            if (S.d_pte) (void)hipMemset(S.d_pte, 0, 8 * n);
-            if (S.d_key) (void)hipMemset(S.d_key, 0, n / 4);
-            if (S.d_out) (void)hipMemset(S.d_out, 0, np * 3 * n * sizeof(uint32_t));
+            if (S.d_slab) (void)hipMemset(S.d_slab, 0, S.slab_bytes);
             (void)hipDeviceSynchronize();
-            void *dev[] = {S.d_rows, S.d_meta, S.d_pte, S.d_key, S.d_out};
+            void *dev[] = {S.d_rows, S.d_meta, S.d_slab};
             for (void *q : dev)
                 if (q) (void)hipFree(q);
             if (S.h_stage)
@@ -912,14 +914,15 @@ static void sym_spec_wipe(Lower &L)
     Lower::SymSpec &S = L.sym;
     const size_t n = L.n, np = L.c().hp.nprimes;
     for (auto &p : S.pre) p = false;
+    if (!S.dirty) return;                          // nothing uploaded or computed since the last wipe
     if (!S.h_pte.empty()) explicit_bzero(S.h_pte.data(), S.h_pte.size() * 8);
     if (!S.h_key.empty()) explicit_bzero(S.h_key.data(), S.h_key.size());
     S.h_pte.clear(), S.h_key.clear();
-    if (!S.cp) return;
-    if (S.d_pte) (void)hipMemsetAsync(S.d_pte, 0, 8 * n, S.cp);
-    if (S.d_key) (void)hipMemsetAsync(S.d_key, 0, n / 4, S.cp);
-    if (S.d_out) (void)hipMemsetAsync(S.d_out, 0, np * 3 * n * sizeof(uint32_t), S.cp);
-    if (S.h_stage) explicit_bzero(S.h_stage, np * 4 * n * sizeof(uint32_t));
+    if (S.cp && S.d_slab) (void)hipMemsetAsync(S.d_slab, 0, S.slab_bytes, S.cp);
+    // staging rows per prime: a | c0 (the ciphertext: public) | ntt_pte | s_save (NTT(m + e), NTT(s): wiped)
+    if (S.h_stage)
+        for (size_t pr = 0; pr < np; pr++) explicit_bzero(S.h_stage + (pr * 4 + 2) * n, 2 * n * sizeof(uint32_t));
+    S.dirty = false;
 }
 
 // windows of the start counters of primes 1 .. np-1 (the estimate of Context::small_batch_plan), as many primes as the
@@ -942,17 +945,22 @@ static void sym_spec_arm(Lower &L, const Parms *parms, const SE_PRNG *shareable)
         for (auto &e : S.ev_kernel) LOWER_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : S.ev_copied) LOWER_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const size_t np = c.hp.nprimes;
-        LOWER_HIP(hipMalloc((void **)&S.d_pte, 8 * n));
-        LOWER_HIP(hipMalloc((void **)&S.d_key, n / 4));
-        LOWER_HIP(hipMalloc((void **)&S.d_out, np * 3 * n * sizeof(uint32_t)));
+        S.slab_bytes = 8 * n + np * 3 * n * sizeof(uint32_t) + n / 4;
+        LOWER_HIP(hipMalloc((void **)&S.d_slab, S.slab_bytes));
+        S.d_pte = (int64_t *)S.d_slab;
+        S.d_out = (uint32_t *)(S.d_slab + 8 * n);
+        S.d_key = S.d_slab + 8 * n + np * 3 * n * sizeof(uint32_t);
         LOWER_HIP(hipHostMalloc((void **)&S.h_stage, np * 4 * n * sizeof(uint32_t), hipHostMallocDefault));
     }
     else
     {
         LOWER_HIP(hipStreamSynchronize(S.st));   // an earlier speculation nobody consumed
         LOWER_HIP(hipStreamSynchronize(S.cp));
-        sym_spec_wipe(L);                        // ... and what an abandoned chain left behind
-        LOWER_HIP(hipStreamSynchronize(S.cp));   // (its memsets run on S.cp; the uploads below do not order against it)
+        if (S.dirty)
+        {
+            sym_spec_wipe(L);                        // what a chain abandoned half-way left behind
+            LOWER_HIP(hipStreamSynchronize(S.cp));   // (its memset runs on S.cp; the uploads below do not order against it)
+        }
     }
     // plan
     double mu = 0.0, var = 0.0;
@@ -1045,6 +1053,7 @@ void ckks_sym_init(const Parms *parms, uint8_t *share_seed_in, uint8_t *seed_in,
     // for the per-prime calls (L.i64 is every operator's scratch)
     const size_t n = L.n;
     put_prng(L, prng);
+    S.dirty = true;
     up(S.d_pte, conj_vals_int, 8 * n);
     seamd::CbdArgs ca{L.seed, L.ctr, L.i8[0], (uint32_t)(n / 16), 1};
     LOWER_HIP(seamd::launch_sample_cbd(ca, nullptr));
@@ -1089,6 +1098,7 @@ void ckks_encode_encrypt_sym(const Parms *parms, const int64_t *conj_vals_int, c
             // (re)compute this prime and the ones the counter chain leads to, from the inputs of THIS call
             LOWER_HIP(hipStreamSynchronize(S.cp));   // staging buffers of an earlier chain may still be in flight
             for (auto &p : S.pre) p = false;
+            S.dirty = true;
             if (!same_pte)
             {
                 up(S.d_pte, conj_vals_int, 8 * n);
