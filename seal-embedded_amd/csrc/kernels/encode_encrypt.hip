@@ -327,9 +327,18 @@ constexpr int enc_quad_stride()
     return MODE == kModeAsym ? 28 : 20;
 }
 
-template <int LOGN, int MODE, bool GENERAL>
-__device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables &T, const EncArgs &A,
-                                            const size_t b, unsigned char *smem)
+// pair form of the fast kernels (encrypt_pair below)
+constexpr int kWgRisky          = 8;   // a coefficient within the guard band of a half-integer
+constexpr double kHalfDelta     = 3.0e-14 * 1.001;
+constexpr size_t kPairParkWords = 5120;   // parked coefficients start here (32-bit words into the dynamic LDS)
+
+// Everything behind the encoder for ONE plaintext whose coefficients k = t + (n/16) e sit in m[]: + error, per prime
+// {representative, NTT, fused ciphertext arithmetic}.  PAIR: the caller transforms two plaintexts per workgroup
+// (encrypt_pair) and parks the second one's coefficients in LDS behind the first 9 216 words -- the transpose region
+// then lives inside the NTT plane (one workgroup barrier more per prime: measured neutral, profiles/r05_ab_qalias28.log).
+template <int LOGN, int MODE, bool GENERAL, bool PAIR, typename MT>
+__device__ __forceinline__ void encrypt_tail(const DevParams &P, const DevTables &T, const EncArgs &A,
+                                             const size_t b, unsigned char *smem, MT (&m)[16], const bool small)
 {
     const int t = thread_index<GENERAL>();
     using G            = XformGeom<LOGN>;
@@ -340,21 +349,7 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
 
     const int np   = P.nprimes;
 
-    using MT = typename std::conditional<GENERAL, int64_t, int32_t>::type;
-    MT m[16];
-    bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
-    int wg;
-    encode_plaintext<LOGN, MT, GENERAL>(P, T, A.values, A.status, b, smem, m, small, wg);
-    if constexpr (!GENERAL)
-    {
-        if (!small)   // workgroup-uniform in the fast form (encode_plaintext)
-        {
-            if (t == 0) A.general[1 + atomicAdd(A.general, 1u)] = (uint32_t)b;
-            return;
-        }
-    }
-
-    // thread t now owns points k = t + (n/16)*e
+    // thread t owns points k = t + (n/16)*e
     if constexpr (MODE == kModeSym)
     {
 #pragma unroll
@@ -389,7 +384,8 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     // workgroup instead of 79, THREE workgroups per CU -- possible since the kernel needs 150 VGPRs (opaque_index
     // above; 206 before).  Fused stage 5.09 -> 4.83 ms per 65 536 (profiles/r04_ab_transform.log).  (The same alias
     // for the symmetric / encode-only forms, 28-word rows: no gain, profiles/r05_ab_qalias28.log.)
-    constexpr bool QALIAS  = MODE == kModeAsym && ASYM3 && !GENERAL;
+    constexpr bool QALIAS  = (MODE == kModeAsym && ASYM3 && !GENERAL) || PAIR;
+    static_assert(!PAIR || (size_t)(G::N / 16) * QSTRIDE <= kPairParkWords, "the transpose region ends below the parked plaintext");
     uint32_t *qlds         = lds32 + (QALIAS ? 0 : (MODE == kModeAsym && ASYM3 ? 3 : 1)) * G::SLOTS;
     auto to_quads = [&](uint32_t (&v)[16]) {
         if constexpr (QUADS) tile_to_quads<QSTRIDE>(v, qlds, t);
@@ -583,6 +579,197 @@ __device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables 
     }
 }
 
+template <int LOGN, int MODE, bool GENERAL>
+__device__ __forceinline__ void encrypt_one(const DevParams &P, const DevTables &T, const EncArgs &A,
+                                            const size_t b, unsigned char *smem)
+{
+    const int t = thread_index<GENERAL>();
+    using MT = typename std::conditional<GENERAL, int64_t, int32_t>::type;
+    MT m[16];
+    bool small;  // wave-uniform: every |m + e| of this wave is below 2 q_min
+    int wg;
+    encode_plaintext<LOGN, MT, GENERAL>(P, T, A.values, A.status, b, smem, m, small, wg);
+    if constexpr (!GENERAL)
+    {
+        if (!small)   // workgroup-uniform in the fast form (encode_plaintext)
+        {
+            if (t == 0) A.general[1 + atomicAdd(A.general, 1u)] = (uint32_t)b;
+            return;
+        }
+    }
+    encrypt_tail<LOGN, MODE, GENERAL, false>(P, T, A, b, smem, m, small);
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the fast (int32) symmetric / encode-only forms at n = 4096 take TWO plaintexts per workgroup and encode
+// them through the half-size transform (transform.cuh, ifft_pair_real_half), keeping the reference's bits by a guard:
+//
+//   * Through stage 10 the lower half's values are the reference's own, bit for bit.  The reference's last stage uses
+//     v, its COMPUTED upper-half value, where we use conj(u); in exact arithmetic they are equal, so the two outputs
+//     of a pair differ by at most |Re v - Re u| + |Im v + Im u| (+ 3 roundings) <= sqrt(2) |v - conj(u)|, and
+//     |v - conj(u)| <= the forward errors of v and of u after 11 stages.  A butterfly row carries a relative error
+//     <= 6u on (|u| + |v|) (sum: u; difference x root: u + 2 sqrt(2) u for the Annex-G product + 2u for libm's
+//     root, u = 2^-53); a stage multiplies the 2-norm by sqrt(2) and the norm of the absolute-value matrix is 2, so
+//     11 stages leave ||x^ - x||_2 <= 11 sqrt(2) 6u ||x||_2 = 1.04e-14 ||x||_2 with ||x||_2 = ||y||_2 / sqrt(2), y =
+//     the exact output vector.  Every output therefore differs from the reference's by less than 2.2e-14 ||y||_2 (incl.
+//     the roundings of the last stage and of the scaling); ||y||_2 = sqrt(n) ||A||_2 = sqrt(2 n sum values^2) exactly.
+//   * kHalfDelta = 3e-14 (x 1.001 for the float accumulation of the sum) is that bound with 36 % of slack -- and the
+//     bound itself assumes every rounding error aligned: the measured maximum deviation is 1.9e-17 ||m||_2, 1 300 times
+//     smaller.  A coefficient whose scaled value lies within delta of a half-integer could round differently from the
+//     reference's: the workgroup then REDOES that plaintext with the full transform (encode_plaintext; about one
+//     plaintext in nine at the bench distribution).  Everything else about the fast form is unchanged: a plaintext
+//     that is not small, or holds a non-finite value, is declined to the general kernel.
+// The second plaintext's coefficients wait in LDS (thread-private slots behind the NTT plane + transpose region)
+// while the first one's primes run.
+// ------------------------------------------------------------------------------------------
+
+// flags of plaintext A in bits 0..7, of plaintext B in bits 8..15 (kWgNotSmall | kWgNonfinite | kWgRisky)
+template <int LOGN>
+__device__ __forceinline__ int encode_pair_half(const DevParams &P, const DevTables &T, const float *values,
+                                                const size_t bA, const size_t bB, unsigned char *smem,
+                                                int32_t (&mA)[16], int32_t (&mB)[16])
+{
+    using G          = XformGeom<LOGN>;
+    constexpr int N  = G::N;
+    constexpr int TH = G::THREADS;
+    static_assert((N / 8) / TH == 2, "two float4 pieces per thread and plaintext");
+    const int t      = threadIdx.x;
+    double *plane    = reinterpret_cast<double *>(smem);
+    float *sv        = reinterpret_cast<float *>(smem);   // A's values at [0, n/2), B's at [n/2, n)
+    float *part      = sv + N;                            // [wave][plaintext] sums of squares
+
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f nf[2]   = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    float ss[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(values + (p ? bB : bA) * (N / 2));
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const int i    = t + k * TH;
+            const float4 v = src[i];
+            nf[p]          = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{0.0f, 0.0f}, nf[p]);
+            nf[p]          = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{0.0f, 0.0f}, nf[p]);
+            ss[p]          = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss[p]))));
+            float *dst     = sv + p * (N / 2);
+            dst[sv_slot(4u * i, LOGN)]      = v.x;
+            dst[sv_slot(4u * i + 1u, LOGN)] = v.y;
+            dst[sv_slot(4u * i + 2u, LOGN)] = v.z;
+            dst[sv_slot(4u * i + 3u, LOGN)] = v.w;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss[0] += __shfl_xor(ss[0], off), ss[1] += __shfl_xor(ss[1], off);
+    if ((t & 63) == 0) part[2 * (t >> 6)] = ss[0], part[2 * (t >> 6) + 1] = ss[1];
+    bool nonfinite[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+    {
+        const float s = nf[p].x + nf[p].y;
+        nonfinite[p]  = s != s;   // this thread staged a NaN or an infinity of plaintext p
+    }
+    __syncthreads();
+    const float ss_all[2] = {(part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7])};
+    double re[16], im[16];
+    {
+        const int Tl    = t & 127;
+        const float *my = sv + (t >> 7) * (N / 2);
+        const uint4 *mp = reinterpret_cast<const uint4 *>(T.gather_map);
+        uint4 m0 = mp[Tl], m1 = mp[TH + Tl];
+        uint32_t packed[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            uint32_t idx = (packed[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+            re[e]        = (double)my[idx];
+            im[e]        = 0.0;
+        }
+    }
+    __syncthreads();
+    ifft_pair_real_half<LOGN>(re, im, T.ifft_w, plane, t);
+
+    int flags = 0;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+    {
+        // |fast - reference| < delta for every scaled coefficient (see above); ||m||_2 = n_inv sqrt(2 n sum values^2)
+        const double delta = kHalfDelta * P.n_inv * sqrt(2.0 * (double)N * (double)ss_all[p]);
+        double amax = 0.0;
+        bool risky  = false;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            const double x = e < 8 ? re[8 * p + e] : im[8 * p + e - 8];
+            const double v = __dmul_rn(x, P.n_inv);
+            const double a = fabs(v);
+            const double g = __dsub_rn(a, trunc(a));        // exact; distance to the rounding boundary = |g - 0.5|
+            risky          = risky || (fabs(__dsub_rn(g, 0.5)) < delta);
+            const double r = round_half_away(v);
+            amax           = fmax(amax, fabs(r));
+            if (p == 0) mA[e] = (int32_t)r; else mB[e] = (int32_t)r;
+        }
+        const bool sm = amax < P.small_bound && !nonfinite[p];
+        flags |= ((sm ? 0 : kWgNotSmall) | (nonfinite[p] ? kWgNonfinite : 0) | (risky ? kWgRisky : 0)) << (8 * p);
+    }
+    return __ockl_wgred_or_i32(flags);
+}
+
+template <int LOGN, int MODE>
+__device__ __forceinline__ void encrypt_pair(const DevParams &P, const DevTables &T, const EncArgs &A,
+                                             const size_t bA, const bool haveB, unsigned char *smem)
+{
+    const int t     = threadIdx.x;
+    const size_t bB = haveB ? bA + 1 : bA;   // an odd batch ends with a workgroup that carries its plaintext twice
+    int32_t m[16], mo[16];                   // A's coefficients / B's
+    const int flags = encode_pair_half<LOGN>(P, T, A.values, bA, bB, smem, m, mo);
+    // Per plaintext: declined (general kernel), or coefficients valid -- after an exact redo when one of them sat in the
+    // guard band (two call sites of the full encoder: a loop over the two register arrays would put them in scratch).
+    int run = 0;
+    auto settle = [&](int32_t (&mm)[16], const int f, const size_t b, const bool live, const int bit) {
+        bool small = !(f & (kWgNotSmall | kWgNonfinite));
+        if (small && (f & kWgRisky) && live)
+        {
+            int wg;   // the full transform decides (it writes the status and may still decline)
+            encode_plaintext<LOGN, int32_t, false>(P, T, A.values, A.status, b, smem, mm, small, wg);
+        }
+        else if (small && live && A.status && t == 0)
+            A.status[b] = 1;
+        if (!small && live && t == 0) A.general[1 + atomicAdd(A.general, 1u)] = (uint32_t)b;
+        run |= (small && live) ? bit : 0;
+    };
+    settle(m, flags & 0xFF, bA, true, 1);
+    settle(mo, (flags >> 8) & 0xFF, bB, haveB, 2);
+    // B's coefficients wait in thread-private LDS slots behind the NTT plane and the transpose region while A's
+    // primes run (ONE call site of the tail: the loop below is not unrolled)
+    uint32_t *park = reinterpret_cast<uint32_t *>(smem) + kPairParkWords + t;
+    __syncthreads();   // an exact redo may still be reading the plane the slots lie in
+    if (run & 2)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; e++) park[e * XformGeom<LOGN>::THREADS] = (uint32_t)mo[e];
+    }
+#pragma nounroll
+    for (int p = 0; p < 2; p++)
+    {
+        if (run & (1 << p)) encrypt_tail<LOGN, MODE, false, true>(P, T, A, p ? bB : bA, smem, m, true);
+        if (p == 0 && (run & 2))
+        {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; e++) m[e] = (int32_t)park[e * XformGeom<LOGN>::THREADS];
+        }
+    }
+}
+
+// two plaintexts per workgroup (encrypt_pair)
+template <int LOGN, int MODE>
+constexpr bool enc_pairs()
+{
+    return LOGN == 12 && MODE != kModeAsym;
+}
+
 // workgroups per CU the register budget is set for (n <= 4096: 256 threads = one wave per SIMD each)
 template <int LOGN, int MODE, bool GENERAL>
 constexpr int enc_blocks()
@@ -598,7 +785,10 @@ __global__ __launch_bounds__(XformGeom<LOGN>::THREADS, (enc_blocks<LOGN, MODE, f
 void k_encode_encrypt(DevParams P, DevTables T, EncArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    encrypt_one<LOGN, MODE, false>(P, T, A, blockIdx.x, smem);
+    if constexpr (enc_pairs<LOGN, MODE>())
+        encrypt_pair<LOGN, MODE>(P, T, A, (size_t)2 * blockIdx.x, (size_t)2 * blockIdx.x + 1 < A.count, smem);
+    else
+        encrypt_one<LOGN, MODE, false>(P, T, A, blockIdx.x, smem);
 }
 
 template <int LOGN, int MODE>
@@ -991,10 +1181,14 @@ static hipError_t launch_enc_mode(const DevParams &P, const DevTables &T, const 
     }
     hipError_t e = hipMemsetAsync(A.general, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
+    EncArgs Af = A;
+    Af.count   = B;
+    if (enc_pairs<LOGN, MODE>()) shmem_fast = std::max(shmem_fast, (kPairParkWords + (size_t)G::N) * sizeof(uint32_t));
+    const unsigned grid_fast = (unsigned)(enc_pairs<LOGN, MODE>() ? (B + 1) / 2 : B);   // two plaintexts per workgroup
     (void)hipFuncSetAttribute((const void *)k_encode_encrypt<LOGN, MODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast);
-    hipLaunchKernelGGL((k_encode_encrypt<LOGN, MODE>), dim3((unsigned)B), dim3(G::THREADS), shmem_fast, st, P, T,
-                       A);
+    hipLaunchKernelGGL((k_encode_encrypt<LOGN, MODE>), dim3(grid_fast), dim3(G::THREADS), shmem_fast, st, P, T,
+                       Af);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the plaintexts the fast form declined (normally none: the workgroups read a zero count and leave)

@@ -23,6 +23,8 @@ struct EncArgs
     uint8_t *compact;    // split kernels only (optional): [B] k_encode_rns -> k_ntt_fuse, 1 = the plaintext
                          // was small and travels as ONE int32 row (in c0's last prime row) instead of np
                          // residue rows
+    size_t count;        // fused kernel: plaintexts of the launch (set by the launcher: n = 4096 symmetric /
+                         // encode-only workgroups take two plaintexts each)
 };
 struct UniformArgs
 {

@@ -338,6 +338,104 @@ __device__ __forceinline__ void ifft_tiles(double (&re)[16], double (&im)[16],
 }
 
 // ------------------------------------------------------------------------------------------
+// HALF-SIZE IFFT of the CKKS slot vector, TWO plaintexts per workgroup (n = 4096, round 6).  The encoder's input is
+// real and reverse-symmetric in stored order, A[n-1-k] = A[k] (ckks_common.c:139-153: slot and conjugate slot of the
+// index map are bit-reversed complements), and every DIF stage i < logn-1 maps the half k < n/2 onto itself (its
+// butterflies pair k with k + 2^i, both below n/2): stages 0 .. logn-2 on the lower half ARE the reference's own
+// operations on those points, bit for bit.  Only the last stage pairs u = X[k] with v = X[k + n/2], and in exact
+// arithmetic v = conj(u), so
+//     out[k]       = u + v             = 2 Re u
+//     out[k + n/2] = (u - v) * W[1]    -> real part -(2 Im u) * Im W[1]            (fft.c:118-141, Annex-G product)
+// The reference computes v from the upper half with its own roundings (libm's root table is mirror-symmetric only up
+// to the last ulp), so its outputs differ from these by a few ulp -- the CALLER detects the coefficients whose rounding
+// to integer could differ and redoes those plaintexts with ifft_tiles (encode_encrypt.hip, encode_pair_half: rigorous
+// bound, exact redo).  46 % of the butterflies of ifft_tiles and half its LDS traffic per plaintext.  A half-size
+// problem fills only 128 register tiles, so a 256-thread workgroup transforms TWO plaintexts side by side (with one
+// plaintext half the waves idle through the register passes and the kernel gains 3 % instead of 10 %): waves 0, 1 run
+// passes 0 and 1 (windows 0 and 4) on plaintext A's 128 lower tiles, waves 2, 3 on plaintext B's; then every thread
+// takes 8 points of A and 8 of B through the three remaining stages.
+// In: thread t holds the real points 16T .. 16T+15 of plaintext t >> 7 in re[] (T = t & 127, im[0] = +0).
+// Out: the REAL outputs t + 256 e of A are re[e] (e < 8), im[e-8] (e >= 8); of B: re[8+e], im[e].
+// `plane` = XformGeom::SLOTS doubles: A's exchange region in the lower half, B's in the upper.
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__device__ __forceinline__ void ifft_pair_real_half(double (&re)[16], double (&im)[16], const double *__restrict__ W,
+                                                    double *plane, int t)
+{
+    static_assert(LOGN == 12, "four waves: two per plaintext in the register passes");
+    using G             = XformGeom<LOGN>;
+    constexpr int N     = 1 << LOGN;
+    constexpr int HALF  = G::SLOTS / 2;
+    static_assert(lds_slot<0, 4>(N / 2 - 1) < HALF && lds_slot<4, 8>(N / 2 - 1) < HALF, "a plaintext's lower half fits its region");
+    const int T   = t & 127;              // tile of this thread in the register passes
+    double *mine  = plane + (t >> 7) * HALF;
+    ifft_pass0_real<LOGN>(re, im, W, T);
+    auto exchange_0_4 = [&](double (&v)[16]) {
+        double *wr = mine + lds_slot<0, 4>(tile_index<0>(T, 0));
+        static_for<0, 16>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            wr[lds_slot<0, 4>(e << 0)] = v[e];
+        });
+        __syncthreads();
+        const double *rd = mine + lds_slot<0, 4>(tile_index<4>(T, 0));
+        static_for<0, 16>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            v[e] = rd[lds_slot<0, 4>(e << 4)];
+        });
+        __syncthreads();
+    };
+    exchange_0_4(re);
+    exchange_0_4(im);
+    ifft_pass<LOGN, 4, 0, 4>(re, im, W, T);
+    // window 4 -> 8: every thread takes points (e << 8) | t, e < 8, of BOTH plaintexts (A into slots 0..7, B into 8..15)
+    auto exchange_4_8 = [&](double (&v)[16]) {
+        double *wr = mine + lds_slot<4, 8>(tile_index<4>(T, 0));
+        static_for<0, 16>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            wr[lds_slot<4, 8>(e << 4)] = v[e];
+        });
+        __syncthreads();
+        const double *rd = plane + lds_slot<4, 8>(tile_index<8>(t, 0));
+        static_for<0, 8>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            v[e]     = rd[lds_slot<4, 8>(e << 8)];
+            v[8 + e] = rd[HALF + lds_slot<4, 8>(e << 8)];
+        });
+        __syncthreads();
+    };
+    exchange_4_8(re);
+    exchange_4_8(im);
+    // stages 8, 9, 10 (bits 0..2 of e): root index (n >> (i+1)) + (k >> (i+1)), uniform over the workgroup
+    static_for<0, 3>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        constexpr int h = N >> (8 + b + 1);
+        static_for<0, (4 >> b)>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const double2 w = *reinterpret_cast<const double2 *>(W + 2 * (h + g));
+            static_for<0, (2 << b)>([&](auto rc) {
+                constexpr int r  = decltype(rc)::value;                       // low bits: butterfly; top bit: plaintext
+                constexpr int e0 = ((r >> b) << 3) | (g << (b + 1)) | (r & ((1 << b) - 1));
+                constexpr int e1 = e0 | (1 << b);
+                double ar = __dsub_rn(re[e0], re[e1]);
+                double ai = __dsub_rn(im[e0], im[e1]);
+                re[e0]    = __dadd_rn(re[e0], re[e1]);
+                im[e0]    = __dadd_rn(im[e0], im[e1]);
+                cmul_annexg<false>(ar, ai, w.x, w.y, re[e1], im[e1]);
+            });
+        });
+    });
+    // stage 11 with v = conj(u)
+    const double w1y = W[3];   // Im W[1]
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const double i2 = __dadd_rn(im[e], im[e]);
+        im[e]           = -__dmul_rn(i2, w1y);
+        re[e]           = __dadd_rn(re[e], re[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // NTT pass: stages for local bits [B_LO, B_HI) of a tile at window C, descending.
 // RW = interleaved (-root mod 2^32, shoup(root)) table of one prime.
 // ------------------------------------------------------------------------------------------

@@ -248,6 +248,32 @@ def test_host_tables_match_oracle_and_golden(pkg, shape):
         pkg.host_tables(3000, 1)
 
 
+def _hot_path_has_no_scratch(root):
+    """k_encode_encrypt<12, 0 | 2> (two plaintexts per workgroup): every scratch instruction of the compiled kernel lies in
+    the exact-redo branch -- laid out behind the kernel's main body, entered by a forward branch -- i.e. none in front of the
+    first prime loop and none inside a loop that carries the NTT (7-op Harvey butterflies: v_mad_u64_u32)."""
+    import subprocess
+    src = os.path.join(root, "seal-embedded_amd", "csrc")
+    out = "/tmp/se_enc_isa.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + src,
+                    "-I" + os.path.join(root, "include"), "-S", "--cuda-device-only",
+                    os.path.join(src, "kernels", "encode_encrypt.hip"), "-o", out], check=True, capture_output=True, timeout=900)
+    isa = open(out).read().split("\n")
+    for mode in (0, 2):
+        start = next(i for i, ln in enumerate(isa) if re.match(r"^_ZN5seamd16k_encode_encryptILi12ELi%dEEEv\w*:" % mode, ln))
+        end = next(i for i in range(start, len(isa)) if isa[i].startswith(".Lfunc_end"))
+        body = isa[start:end]
+        scratch = [i for i, ln in enumerate(body) if "scratch_" in ln]
+        mads = [i for i, ln in enumerate(body) if "v_mad_u64_u32" in ln]
+        assert mads, mode
+        if not scratch:
+            continue
+        # the hot path: everything up to the end of the FIRST block of butterflies (the tail's prime loop)
+        gaps = [j for j in range(1, len(mads)) if mads[j] - mads[j - 1] > 600]
+        first_loop_end = mads[gaps[0] - 1] if gaps else mads[-1]
+        assert min(scratch) > first_loop_end, (mode, min(scratch), first_loop_end)
+
+
 def test_hot_kernels_keep_their_register_budget():
     """Regression guard for the register budgets the throughput numbers rest on (hipcc
     -Rpass-analysis=kernel-resource-usage, tools/resource_usage.py): the fast fused kernels of
@@ -268,7 +294,14 @@ def test_hot_kernels_keep_their_register_budget():
     for logn in (10, 11, 12, 13):
         for mode in (0, 1, 2):
             vgpr, scratch, occ = rows[f"k_encode_encrypt<{logn}, {mode}>"]
-            assert scratch == 0, (logn, mode, scratch)
+            if logn == 12 and mode != 1:
+                # round 6: the pair form keeps the SECOND plaintext's coefficients in registers across the exact redo of a
+                # plaintext in the guard band (about 1 workgroup in 25): that branch may spill, the hot path must not --
+                # _hot_path_has_no_scratch below reads the ISA
+                assert scratch <= 96, (logn, mode, scratch)
+            else:
+                assert scratch == 0, (logn, mode, scratch)
+    _hot_path_has_no_scratch(root)
     for mode in (0, 2):
         assert rows[f"k_encode_encrypt<12, {mode}>"][0] <= 128 and rows[f"k_encode_encrypt<12, {mode}>"][2] >= 4
     assert rows["k_encode_encrypt<12, 1>"][0] <= 168 and rows["k_encode_encrypt<12, 1>"][2] >= 3

@@ -700,6 +700,49 @@ def test_encode_only_config5(env):
             assert (got[b, j] == o.ntt(o.reduce_pte(m, j), j)).all()
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 130, 257])
+def test_pair_form_of_the_fused_kernels_on_odd_batches(env, B):
+    """Round 6: the fast symmetric / encode-only kernels at n = 4096 take TWO plaintexts per workgroup (half-size
+    transform + guard band + exact redo, encode_encrypt.hip: encrypt_pair).  Odd batches end with a workgroup that holds
+    one plaintext; a pair may consist of one ordinary and one declined (large / NaN) plaintext in either position.
+    Every record against the oracle, encode-only and fused symmetric, with pte / ntt_pte / status."""
+    from oracle.pyoracle import Oracle
+    torch = env["torch"]
+    n, npr = 4096, 3
+    o = Oracle(n, npr)
+    sk = V.secret_key(n, seed=5)
+    vals = V.bench_values(B, n, first=4200 + B)
+    if B >= 3:
+        vals[1] *= 60.0                 # not small: the general kernel, second of its pair
+        vals[B - 1, 7] = float("nan")   # non-finite, last plaintext (first of a one-plaintext workgroup when B is odd)
+    if B >= 130:
+        vals[64] *= 1000.0              # first of its pair
+    ss, sd = V.bench_seeds(B, first=4200 + B)
+    ctx = env["pkg"].Context(n, npr)
+    ctx.set_secret_key(sk)
+    ctx.set_pipeline(True, False)       # the fused kernel whatever the batch
+    out = torch.zeros((B, npr, n), dtype=torch.int32, device=env["dev"])
+    pte = torch.zeros((B, n), dtype=torch.int64, device=env["dev"])
+    st = torch.zeros(B, dtype=torch.uint8, device=env["dev"])
+    ctx.encode_ntt(dev_t(env, vals), out, pte=pte, status=st)
+    c0 = torch.zeros_like(out)
+    c1 = torch.zeros_like(out)
+    npte = torch.zeros_like(out)
+    st2 = torch.zeros_like(st)
+    ctx.encrypt_sym(dev_t(env, vals), dev_t(env, ss), dev_t(env, sd), c0, c1, npte, None, st2)
+    torch.cuda.synchronize()
+    got, gpte, g0, g1 = host_u32(out), pte.cpu().numpy(), host_u32(c0), host_u32(c1)
+    for b in range(B):
+        ok, m = o.encode(vals[b])
+        assert int(st[b]) == int(ok) and int(st2[b]) == int(ok), b
+        assert np.array_equal(gpte[b], m), b
+        for j in range(npr):
+            assert (got[b, j] == o.ntt(o.reduce_pte(m, j), j)).all(), (b, j)
+        r = o.encrypt_sym(vals[b], ss[b].tobytes(), sd[b].tobytes(), sk)
+        assert (g0[b] == r["c0"]).all() and (g1[b] == r["c1"]).all(), b
+    ctx.close()
+
+
 def test_encode_coefficient_of_exactly_2_pow_63(env):
     """A coefficient of exactly +-2^63 is NOT an overflow for the reference (it rejects only
     |coeff| > 2^63, ckks_common.c:195) and its build converts +2^63 to INT64_MIN: a constant vector
