@@ -700,7 +700,7 @@ def test_encode_only_config5(env):
             assert (got[b, j] == o.ntt(o.reduce_pte(m, j), j)).all()
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 7, 130, 257])
+@pytest.mark.parametrize("B", [1, 3, 130])
 def test_pair_form_of_the_fused_kernels_on_odd_batches(env, B):
     """Round 6: the fast symmetric / encode-only kernels at n = 4096 take TWO plaintexts per workgroup (half-size
     transform + guard band + exact redo, encode_encrypt.hip: encrypt_pair).  Odd batches end with a workgroup that holds
