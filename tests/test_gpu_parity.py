@@ -715,6 +715,12 @@ def test_pair_form_of_the_fused_kernels_on_odd_batches(env, B):
     if B >= 3:
         vals[1] *= 60.0                 # not small: the general kernel, second of its pair
         vals[B - 1, 7] = float("nan")   # non-finite, last plaintext (first of a one-plaintext workgroup when B is odd)
+        # an EXACT rounding tie: a constant slot vector v = 75 / 2^26 encodes to m_0 = v * 2^25 = 37.5 exactly (sums of
+        # equal values and the power-of-two scaling are exact), every other coefficient ~0: the half-size transform must
+        # flag it (distance 0 to the half-integer) and the full transform must round it half away from zero as round() does
+        vals[0, :] = np.float32(75.0 / 2.0 ** 26)
+    if B >= 130:
+        vals[5, :] = np.float32(-(2 * 4001 + 1) / 2.0 ** 26)   # a negative tie, first of its pair
     if B >= 130:
         vals[64] *= 1000.0              # first of its pair
     ss, sd = V.bench_seeds(B, first=4200 + B)
