@@ -1164,9 +1164,15 @@ def test_overflow_reports_failed_plaintexts(env):
 def _compare_all_with_oracle(c0, c1, oracle_chunk, B, chunk=4096):
     """EVERY ciphertext of a full batch against the threaded oracle, chunk by chunk (bounded host
     memory): exact element-wise equality of the c0 and c1 records."""
-    for lo in range(0, B, chunk):
-        hi = min(B, lo + chunk)
-        ok, e0, e1 = oracle_chunk(lo, hi)
+    # the oracle's C threads work on chunk k + 1 while this thread copies chunk k back and compares it
+    from concurrent.futures import ThreadPoolExecutor
+    spans = [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
+    pool = ThreadPoolExecutor(1)
+    nxt = pool.submit(oracle_chunk, *spans[0])
+    for i, (lo, hi) in enumerate(spans):
+        ok, e0, e1 = nxt.result()
+        if i + 1 < len(spans):
+            nxt = pool.submit(oracle_chunk, *spans[i + 1])
         assert ok
         g0 = host_u32(c0[lo:hi])
         assert np.array_equal(g0, e0), f"c0 differs in ciphertexts [{lo},{hi})"
@@ -1176,6 +1182,7 @@ def _compare_all_with_oracle(c0, c1, oracle_chunk, B, chunk=4096):
             assert np.array_equal(g1, e1), f"c1 differs in ciphertexts [{lo},{hi})"
             del g1
         del e1
+    pool.shutdown()
 
 
 @pytest.mark.parametrize("form", ["dispatch"])
