@@ -721,6 +721,13 @@ def test_pair_form_of_the_fused_kernels_on_odd_batches(env, B):
         vals[0, :] = np.float32(75.0 / 2.0 ** 26)
     if B >= 130:
         vals[5, :] = np.float32(-(2 * 4001 + 1) / 2.0 ** 26)   # a negative tie, first of its pair
+        # ties decided by ROUNDING NOISE: one non-zero slot v = (2k+1) / 2^15 encodes to m_j = (k + 0.5) cos(phi_j) -- the
+        # coefficients with |cos| = 1 land within ~1e-13 of a half-integer after 12 butterfly stages, on whichever side
+        # the reference's own rounding errors put them.  Only the full transform can reproduce that; the half-size form
+        # must flag these plaintexts (guard band ~1e-10 here)
+        for row, slot, k in ((6, 0, 50), (7, 17, 12345), (8, 2047, 3)):
+            vals[row, :] = 0.0
+            vals[row, slot] = np.float32((2 * k + 1) / 2.0 ** 15)
     if B >= 130:
         vals[64] *= 1000.0              # first of its pair
     ss, sd = V.bench_seeds(B, first=4200 + B)
