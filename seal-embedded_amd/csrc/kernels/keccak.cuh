@@ -313,16 +313,25 @@ __device__ __forceinline__ void prng_absorb_half(KeccakHalf &s, const uint32_t (
 // 8-lane group, two planes per 16-lane DPP row, planes 0..4 = lanes 0..39, the rest of the wave holds zeros.
 // Each group is [4' 0 1 2 3 4 0' 1']: lane 0 is a copy of column 4, lanes 6, 7 copies of columns 0, 1, so that
 // the in-plane neighbours x-1, x+1, x+2 of every primary lane are plain DPP row shifts (no wrap handling
-// except C[x+1] of column 4, taken from 4 lanes to the left).  Per round:
+// except for column 4, whose right-hand copies are stale after chi).  Per round:
 //   theta  parity over the planes: v_xor_dpp row_ror:8 (the two planes of a row), then v_permlane16_swap and
-//          v_permlane32_swap (gfx950) fold the rows: 7 instructions per half, no LDS;
-//          D = C[x-1] ^ rol1(C[x+1]) with row_shr:1 / row_shl:1; A ^= D & valid (one v_bitop3)
+//          v_permlane32_swap (gfx950) fold the rows of BOTH halves together: 9 instructions, no LDS;
+//          D and A ^= D: 2 v_alignbit + 6 bank- / row-masked v_xor_dpp (wave_keccak_round)
 //   rho    one 64-bit rotation by a per-lane amount: 2 v_cndmask (halves swapped for R >= 32) + 2 v_alignbit
-//   pi     one ds_bpermute_b32 per half (a fixed permutation; it also refreshes the copy lanes)
-//   chi    B[x+1], B[x+2] by row_shl:1 / row_shl:2, one v_bitop3 per half;  iota on the lane of (0, 0)
-// About 40 instructions per round instead of 190: a permutation takes ~3 us instead of ~9-10 us of a lone
-// wave, at 13x the work per state -- for launches of at most a few waves per SIMD (a single se_encrypt call,
-// batches of up to ~2 000 ciphertexts incl. the virtual ones of the prime speculation).
+//   pi     one ds_bpermute_b32 per half (a fixed permutation; it also refreshes the copy lanes and re-zeroes
+//          lanes 40..47)
+//   chi    B[x+1], B[x+2] by row_shl:1 / row_shl:2, one v_bitop3 per half;  iota on the lane of (0, 0), skipped for
+//          a zero half of the constant
+// A lone wave pays one issue slot (~4.5 cycles at best) for EVERY instruction, scalar ones and s_nop included, so the
+// count that matters is all of them: 38.6 per round (28.6 VALU, 2 DS, 2 s_waitcnt, 6 s_nop for the DPP / permlane
+// read-after-write wait states), straight-line with the round constants as literals.  Round 5's form was 38 VALU
+// + 2 DS + 6 s_nop + 9 scalar (constant fetch through s_getpc / s_load, loop, waits) = 55, and its s_waitcnt also sat
+// out the scalar load; round 6 measured each step inside one call (profiles/r06_ab_wave_keccak.log): joint parity
+// 55 -> 47 (-10 % single-call uniform sampler), unrolled with literal constants -> 42 (-15 %), masked-DPP theta
+// -> 38.6 (-20 %: 476 -> 377 us for the 121 permutations of
+// sample_poly_uniform at n = 4096, ~3.1 us per permutation incl. its emit; the lane form takes ~9-10 us as a lone
+// wave).  13x the work per state of the lane form -- for launches of at most a few waves per SIMD (a single
+// se_encrypt call, batches of up to ~2 000 ciphertexts incl. the virtual ones of the prime speculation).
 // ------------------------------------------------------------------------------------------
 struct WaveKeccak
 {
@@ -330,10 +339,8 @@ struct WaveKeccak
     // per-lane constants (set up once per kernel by wave_keccak_init)
     uint32_t sh;          // rho: v_alignbit amount
     uint32_t pi_addr;     // pi: 4 * source lane for ds_bpermute
-    uint32_t valid;       // all-ones on lanes of planes 0..4
     uint32_t iota;        // all-ones on the primary lane of state lane (0, 0)
-    bool swap;            // rho: rotation amount >= 32 (or == 0): halves swapped first
-    bool col4;            // primary lane of column 4: C[x+1] comes from lane - 4
+    uint64_t swap;        // rho: lane mask of the lanes whose rotation amount is >= 32 (or == 0): halves swapped first
     int index;            // x + 5 y on primary lanes of planes 0..4, -1 elsewhere
 };
 
@@ -347,19 +354,18 @@ __device__ __forceinline__ void wave_keccak_init(WaveKeccak &k, int lane)
     const bool in_state = y < 5;
     const bool primary  = in_state && g >= 1 && g <= 5;
     k.index = primary ? x + 5 * y : -1;
-    k.valid = in_state ? 0xFFFFFFFFu : 0u;
     k.iota  = (lane == 1) ? 0xFFFFFFFFu : 0u;
-    k.col4  = g == 5;
     const int R = in_state ? kKeccakRho[x + 5 * y] : 0;
     // rol64 by R on (lo, hi): for R in 1..31 lo' = alignbit(lo, hi, 32 - R), hi' = alignbit(hi, lo, 32 - R);
     // for R >= 32 the same on swapped halves with R - 32; R == 0 is "swapped, amount 0" (alignbit by 0 yields
     // its second source)
-    k.swap = (R >= 32) || (R == 0);
+    k.swap = __builtin_amdgcn_ballot_w64((R >= 32) || (R == 0));
     k.sh   = (uint32_t)((32 - (R & 31)) & 31);
     // pi: B[x'][y'] = rol(A[x][y]) with x' = y, y' = 2x + 3y  =>  this lane (x', y') pulls from the primary lane of
     // x = 3 y' + x' (mod 5), y = x'
     const int xs = (3 * y + x) % 5, ys = x;
-    k.pi_addr = in_state ? (uint32_t)(4 * (8 * ys + xs + 1)) : (uint32_t)(4 * lane);
+    // (lanes 40..47 pull the always-zero lane 63: theta leaves the column parities in them, see wave_keccak_round)
+    k.pi_addr = in_state ? (uint32_t)(4 * (8 * ys + xs + 1)) : (uint32_t)(4 * (lane < 48 ? 63 : lane));
     k.lo = k.hi = 0;
 }
 
@@ -369,47 +375,102 @@ __device__ __forceinline__ uint32_t dpp_row(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 
-// xor over the five planes of every column, valid on every lane of planes 0..4 (and beyond)
-__device__ __forceinline__ uint32_t wave_column_parity(uint32_t v)
+// xor over the five planes of every column, valid on every lane of planes 0..4 (and beyond), for BOTH halves at once
+// (round 6): the row-folding steps work on a register PAIR, so the low and the high
+// half share them -- permlane16_swap(tl, th) leaves [L0 H0 L2 H2] / [L1 H1 L3 H3] (rows), their xor has the low half's
+// partial parities in the even rows and the high half's in the odd rows; one permlane32_swap folds the wave halves of
+// both; a last permlane16_swap of the result with itself deals the even rows (C_lo) to every row of one register and
+// the odd rows (C_hi) to every row of the other.  9 instructions instead of 14.
+__device__ __forceinline__ void wave_column_parity2(uint32_t lo, uint32_t hi, uint32_t &clo, uint32_t &chi_)
 {
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-    uint32_t t = v ^ dpp_row<0x128>(v);                               // row_ror:8: the two planes of a row
-    u2 r       = __builtin_amdgcn_permlane16_swap(t, t, false, false);  // {rows 0,0,2,2 ; rows 1,1,3,3}
-    t          = r.x ^ r.y;                                             // rows 0^1 and 2^3
-    r          = __builtin_amdgcn_permlane32_swap(t, t, false, false);  // {lower, lower ; upper, upper}
-    return r.x ^ r.y;
+    const uint32_t tl = lo ^ dpp_row<0x128>(lo), th = hi ^ dpp_row<0x128>(hi);   // row_ror:8: the two planes of a row
+    u2 r              = __builtin_amdgcn_permlane16_swap(tl, th, false, false);  // {L0 H0 L2 H2 ; L1 H1 L3 H3}
+    const uint32_t z  = r.x ^ r.y;                                               // L01 H01 L23 H23
+    r                 = __builtin_amdgcn_permlane32_swap(z, z, false, false);    // {lower, lower ; upper, upper}
+    const uint32_t w  = r.x ^ r.y;                                               // Clo Chi Clo Chi
+    r                 = __builtin_amdgcn_permlane16_swap(w, w, false, false);    // {Clo x 4 ; Chi x 4}
+    clo  = r.x;
+    chi_ = r.y;
 }
 
-__device__ __forceinline__ void wave_keccak_round(WaveKeccak &k, uint32_t rclo, uint32_t rchi)
+// Keccak round constant r from the degree-8 LFSR of FIPS 202 (3.2.5), at compile time: the rounds of the wave form
+// are instantiated with their constants (below), so nothing is loaded and a zero half costs nothing.
+constexpr uint64_t keccak_round_constant(int r)
+{
+    uint64_t rc = 0;
+    uint32_t R  = 1;
+    for (int i = 0; i < 7 * r; i++) R = ((R << 1) ^ ((R >> 7) * 0x71u)) & 0xFFu;
+    for (int j = 0; j < 7; j++)
+    {
+        if (R & 1u) rc |= 1ull << ((1 << j) - 1);
+        R = ((R << 1) ^ ((R >> 7) * 0x71u)) & 0xFFu;
+    }
+    return rc;
+}
+
+static_assert(keccak_round_constant(0) == 0x0000000000000001ull && keccak_round_constant(2) == 0x800000000000808aull &&
+                  keccak_round_constant(12) == 0x000000008000808bull &&
+                  keccak_round_constant(23) == 0x8000000080008008ull,
+              "round constants (kKeccakRC rows 0, 2, 12, 23)");
+
+template <uint32_t RCLO, uint32_t RCHI>
+__device__ __forceinline__ void wave_keccak_round(WaveKeccak &k)
 {
     // theta
-    const uint32_t clo = wave_column_parity(k.lo), chi_ = wave_column_parity(k.hi);
-    // C[x+1]: lane + 1, or lane - 4 for column 4 (both fetched unconditionally: a DPP move under a
-    // lane-dependent condition would be compiled into an exec-masked branch)
-    const uint32_t plo_a = dpp_row<0x101>(clo), plo_b = dpp_row<0x114>(clo);
-    const uint32_t phi_a = dpp_row<0x101>(chi_), phi_b = dpp_row<0x114>(chi_);
-    const uint32_t plo = k.col4 ? plo_b : plo_a, phi = k.col4 ? phi_b : phi_a;
-    const uint32_t dlo = dpp_row<0x111>(clo) ^ __builtin_amdgcn_alignbit(plo, phi, 31);   // C[x-1] ^ rol1(C[x+1])
-    const uint32_t dhi = dpp_row<0x111>(chi_) ^ __builtin_amdgcn_alignbit(phi, plo, 31);
-    uint32_t alo = __builtin_amdgcn_bitop3_b32(k.lo, dlo, k.valid, 0x78);   // a ^ (b & c)
-    uint32_t ahi = __builtin_amdgcn_bitop3_b32(k.hi, dhi, k.valid, 0x78);
-    // rho
-    const uint32_t a = k.swap ? ahi : alo, b = k.swap ? alo : ahi;
-    const uint32_t rlo = __builtin_amdgcn_alignbit(a, b, k.sh), rhi = __builtin_amdgcn_alignbit(b, a, k.sh);
+    uint32_t clo, chi_;
+    wave_column_parity2(k.lo, k.hi, clo, chi_);
+    // D[x] = C[x-1] ^ rol1(C[x+1]) and A ^= D in eight instructions.  With G[g] = C[c(g)] ^ rol1(C[c(g)+2]) on group
+    // lanes g = 0..4 (columns c = 4, 0, 1, 2, 3), D of the primary lane g is G[g-1].  C[c+2] sits two lanes to the
+    // right for g = 0..3 and three lanes to the LEFT for g = 4 (the copy lanes right of column 4 are stale after
+    // chi): the row_shr:3 form is written to every lane, then the row_shl:2 form overwrites DPP banks 0 and 2
+    // (g = 0..3 of both groups of a row; bank_mask 0x5) -- g = 4 keeps the first, g = 5..7 are never read.  The
+    // apply is a v_xor_b32_dpp in place with row_mask 0x7: row 3 (lanes 48..63) is not written and stays zero, and
+    // lanes 40..47, which do pick up C, are re-zeroed by pi (they pull lane 63) before anything reads them.  The
+    // compiler forms neither masked DPP, hence the asm; it does not see the DPP operands in there either, so the
+    // two wait states a DPP read needs after a VALU write of the same register are placed by hand (s_nop 0 + the
+    // other half's instruction).
+    // rho rides in the same block (one 64-bit rotation by a per-lane amount: halves swapped under the wave-uniform
+    // lane mask k.swap, then two v_alignbit): with it outside, the compiler puts one more s_nop behind the block.
+    uint32_t elo, ehi, glo, ghi, rlo, rhi;
+    asm("v_alignbit_b32 %2, %8, %9, 31\n\t"
+        "v_alignbit_b32 %3, %9, %8, 31\n\t"
+        "s_nop 0\n\t"
+        "v_xor_b32_dpp %4, %2, %8 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_xor_b32_dpp %5, %3, %9 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_xor_b32_dpp %4, %2, %8 row_shl:2 row_mask:0xf bank_mask:0x5\n\t"
+        "v_xor_b32_dpp %5, %3, %9 row_shl:2 row_mask:0xf bank_mask:0x5\n\t"
+        "s_nop 0\n\t"
+        "v_xor_b32_dpp %0, %4, %0 row_shr:1 row_mask:0x7 bank_mask:0xf\n\t"
+        "v_xor_b32_dpp %1, %5, %1 row_shr:1 row_mask:0x7 bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %2, %0, %1, %10\n\t"   // a = swap ? hi : lo
+        "v_cndmask_b32_e64 %3, %1, %0, %10\n\t"   // b = swap ? lo : hi
+        "v_alignbit_b32 %6, %2, %3, %11\n\t"
+        "v_alignbit_b32 %7, %3, %2, %11"
+        : "+v"(k.lo), "+v"(k.hi), "=&v"(elo), "=&v"(ehi), "=&v"(glo), "=&v"(ghi), "=&v"(rlo), "=&v"(rhi)
+        : "v"(clo), "v"(chi_), "s"(k.swap), "v"(k.sh));
     // pi
     const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)k.pi_addr, (int)rlo);
     const uint32_t bhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)k.pi_addr, (int)rhi);
     // chi, iota
     k.lo = chi3(blo, dpp_row<0x101>(blo), dpp_row<0x102>(blo));
     k.hi = chi3(bhi, dpp_row<0x101>(bhi), dpp_row<0x102>(bhi));
-    k.lo = __builtin_amdgcn_bitop3_b32(k.lo, k.iota, rclo, 0x78);
-    k.hi = __builtin_amdgcn_bitop3_b32(k.hi, k.iota, rchi, 0x78);
+    if constexpr (RCLO != 0) k.lo = __builtin_amdgcn_bitop3_b32(k.lo, k.iota, RCLO, 0x78);
+    if constexpr (RCHI != 0) k.hi = __builtin_amdgcn_bitop3_b32(k.hi, k.iota, RCHI, 0x78);
 }
 
+// All 24 rounds straight-line.  The rolled form (two rounds per iteration, constants fetched from kKeccakRC) spent 12
+// of its 47 instructions per round on scalar work -- s_getpc / s_add / s_addc / s_load for the constant, the loop
+// counter and branch -- and a lone wave pays a full issue slot (~4.5 cycles) for every one of them.
+template <int R = 0>
 __device__ __forceinline__ void wave_keccak_f1600(WaveKeccak &k)
 {
-#pragma unroll 2
-    for (int r = 0; r < 24; r++) wave_keccak_round(k, kKeccakRC[r][0], kKeccakRC[r][1]);
+    if constexpr (R < 24)
+    {
+        constexpr uint64_t rc = keccak_round_constant(R);
+        wave_keccak_round<(uint32_t)rc, (uint32_t)(rc >> 32)>(k);
+        wave_keccak_f1600<R + 1>(k);
+    }
 }
 
 // The state prng_absorb() builds (seed[64] || le64(ctr), SHAKE256 padding), spread over the wave: `seed`
