@@ -280,3 +280,34 @@ def test_compiled_sync_kernels_keep_the_barrier_contract():
     for name in SYNC_KERNELS:
         m = re.search(r"\.amdhsa_kernel _ZN5seamd\d+" + name + r"E\w*\n(?:.*\n){0,6}?\s+\.amdhsa_private_segment_fixed_size (\d+)", meta)
         assert m and int(m.group(1)) == 0, (name, m and m.group(1))
+
+
+def test_wave_form_round_constants_are_the_table():
+    """The wave-cooperative rounds take their constants from a constexpr LFSR (keccak.cuh, keccak_round_constant:
+    FIPS 202 section 3.2.5) as template arguments instead of loading kKeccakRC; the header static_asserts four rows.
+    Here: the same LFSR, transcribed, against ALL 24 rows of the table the other forms load (and against the
+    constants hashlib's SHAKE256 implies: test_generated_blocks_compute_shake256 runs the table)."""
+    src = open(os.path.join(ROOT, "seal-embedded_amd", "csrc", "kernels", "keccak.cuh")).read()
+    body = src[src.index("kKeccakRC[24][2] = {"):]
+    body = body[:body.index("};")]
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-fA-F]{8})u", body)]
+    assert len(words) == 48
+    table = [words[2 * r] | (words[2 * r + 1] << 32) for r in range(24)]
+
+    def lfsr_rc(r):
+        rc, R = 0, 1
+        step = lambda R: ((R << 1) ^ ((R >> 7) * 0x71)) & 0xFF
+        for _ in range(7 * r):
+            R = step(R)
+        for j in range(7):
+            if R & 1:
+                rc |= 1 << ((1 << j) - 1)
+            R = step(R)
+        return rc
+
+    assert [lfsr_rc(r) for r in range(24)] == table
+    # the header's own transcription has the same shape (guards against an edit of one and not the other)
+    fn = src[src.index("constexpr uint64_t keccak_round_constant(int r)"):]
+    fn = fn[:fn.index("static_assert")]
+    assert "((R << 1) ^ ((R >> 7) * 0x71u)) & 0xFFu" in fn and "1ull << ((1 << j) - 1)" in fn and "7 * r" in fn
+    assert "wave_keccak_round<(uint32_t)rc, (uint32_t)(rc >> 32)>(k)" in src
