@@ -3,14 +3,18 @@
 n = 4096 x 3), 300 calls enqueued back to back: host time to enqueue a step vs time per step once the device has
 drained, and the latency of a call that is synchronised every time.  Round 6 (MI355X): 50 us enqueue vs 105 us per
 step at C1 -- the device, not the host, sets the pace; 159 vs 420 us at n = 4096 x 3; synchronised calls 133 / 416 us.
-GPU box only:  python tools/small_step_probe.py"""
+GPU box only:  python tools/small_step_probe.py [n nprimes]"""
 import os, sys, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "tests")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch, numpy as np
 from __graft_entry__ import load_package
 pkg = load_package()
 dev = torch.device("cuda:0")
-for (n, npr) in ((1024, 1), (4096, 3)):
+shapes = [(1024, 1), (4096, 3), (16384, 6)]
+if len(sys.argv) > 2:
+    shapes = [(int(sys.argv[1]), int(sys.argv[2]))]
+for (n, npr) in shapes:
     ctx = pkg.Context(n, npr, 0)
     B = 1
     g = torch.Generator(device="cpu"); g.manual_seed(1)
