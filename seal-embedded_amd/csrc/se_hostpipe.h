@@ -69,6 +69,8 @@ struct HostPipe
     size_t ring_bytes           = 0;
     void *d_status              = nullptr;
     size_t status_cap           = 0;
+    uint8_t *h_status           = nullptr;   // pinned: the status bytes come back on the copy stream, behind the last piece
+    size_t h_status_cap         = 0;
     hipStream_t compute = nullptr, copy = nullptr;
     CopyPool *pool      = nullptr;
     size_t chunk_override = 0;  // test hook: ciphertexts per chunk (0 = automatic)
